@@ -1,0 +1,114 @@
+"""ctypes front-end of oracle/fq_oracle.c (numpy in, numpy out) -- TEST INFRASTRUCTURE ONLY.
+
+16-bit float tensors travel as raw uint16 bit patterns, fp32 as float32.  See fq_oracle.c
+for the reference lines each entry point restates and for the parity status (pinned by
+tests/golden/*.npz).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfq_oracle.so")
+DTYPES = {"fp32": 0, "bf16": 1, "fp16": 2}
+SEM_CPU, SEM_DEVICE = 0, 1
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "fq_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libfq_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        L.fqo_sym_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32]
+        L.fqo_asym_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32]
+        L.fqo_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32, i32]
+        L.fqo_w12_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32]
+        for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version):
+            f.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _check(x, dtype):
+    want = np.float32 if dtype == "fp32" else np.uint16
+    if x.dtype != want:
+        raise TypeError(f"{dtype} data must be {want}, got {x.dtype}")
+    return np.ascontiguousarray(x)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def sym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
+    """-> (y, idx int32 or None, scale float32[rows]); x is any-shape array of rows*cols elements."""
+    x = _check(x, dtype)
+    assert x.size == rows * cols
+    y = np.empty_like(x)
+    idx = np.empty(x.shape, np.int32) if want_idx else None
+    scale = np.empty(rows, np.float32)
+    rc = lib().fqo_sym_fwd(_p(x), _p(y), _p(idx), _p(scale), rows, cols, bits, DTYPES[dtype], sem)
+    if rc:
+        raise ValueError(f"fqo_sym_fwd rc={rc}")
+    return y, idx, scale
+
+
+def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
+    """-> (y, idx, alpha[rows], beta[rows])"""
+    x = _check(x, dtype)
+    assert x.size == rows * cols
+    y = np.empty_like(x)
+    idx = np.empty(x.shape, np.int32) if want_idx else None
+    alpha = np.empty(rows, np.float32)
+    beta = np.empty(rows, np.float32)
+    rc = lib().fqo_asym_fwd(_p(x), _p(y), _p(idx), _p(alpha), _p(beta), rows, cols, bits, DTYPES[dtype], sem)
+    if rc:
+        raise ValueError(f"fqo_asym_fwd rc={rc}")
+    return y, idx, alpha, beta
+
+
+def ste_bwd(g, x, lo, hi, dtype):
+    g, x = _check(g, dtype), _check(x, dtype)
+    assert g.size == x.size
+    gx = np.empty_like(g)
+    rc = lib().fqo_ste_bwd(_p(g), _p(x), _p(gx), g.size, lo, hi, DTYPES[dtype])
+    if rc:
+        raise ValueError(f"fqo_ste_bwd rc={rc}")
+    return gx
+
+
+def w12_fwd(w, rows, cols, w_bits, dtype, scale_in=None):
+    """1-/2-bit weight branch of QuantizeLinear -> (q, scale[rows])"""
+    w = _check(w, dtype)
+    q = np.empty_like(w)
+    sc = np.empty(rows, np.float32)
+    si = None if scale_in is None else np.ascontiguousarray(scale_in, np.float32)
+    rc = lib().fqo_w12_fwd(_p(w), _p(q), _p(sc), _p(si), rows, cols, w_bits, DTYPES[dtype])
+    if rc:
+        raise ValueError(f"fqo_w12_fwd rc={rc}")
+    return q, sc
+
+
+def rows_cols(shape, layerwise):
+    """How the reference's granularity rules map a tensor shape to [rows, cols]
+    (utils_quant.py:50-70): layerwise -> one row; ndim<=3 -> last dim; 4-D -> (d0*d1, d2*d3)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    if layerwise:
+        return 1, n
+    if len(shape) <= 3:
+        cols = shape[-1] if len(shape) else 1
+        return (n // cols if cols else 0), cols
+    if len(shape) == 4:
+        return shape[0] * shape[1], shape[2] * shape[3]
+    raise ValueError("ndim >= 5")  # utils_quant.py:70

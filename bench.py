@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- fake-quant fwd+bwd throughput on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload at N=1 (BASELINE.json `metric`: "fake-quant fwd+bwd Gelem/s & achieved HBM GB/s,
+4096x11008 bf16 W4A8"; it is the per-tensor hot path of configs[1], LLaMA-7B W4-A8-KV4):
+one *step* is one pass of the hot path over one batch of synthetic tensors, i.e.
+
+    W4 leg: SymQuantizer fwd + STE bwd on a weight-style  [4096, 11008] bf16 tensor (down_proj.weight)
+    A8 leg: SymQuantizer fwd + STE bwd on an activation-style [4096, 11008] bf16 tensor
+
+through the product's own autograd Functions' kernels (C ABI, current stream).  Inputs are resident
+in HBM before the timed region; the step rotates over several buffer sets (> 256 MiB apart) so the
+Infinity Cache cannot serve re-reads.  `value` = elements processed per second, whole job.
+
+The op is per-tensor and does not shard ("replicas only"): with --gpus N every rank runs
+the same step on its own GPU, no data-path collective; value = N * per-rank elements / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (STE backward): algorithmic bytes / live HIP-event launch time vs 8 TB/s
+  kernels       the same for every kernel of the step
+  cpu_baseline  the reference's CPU path (eager op chain, oracle/eager_chain.py) timed on this box's host
+                cores on a bounded sample -- rank 0, N=1 only
+  gpu_eager     the reference's eager op chain run on this GPU (9+5 launches): the like-for-like "before"
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS, COLS = 4096, 11008
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FWD_BYTES_PER_ELEM = 4   # bf16: read x + write y              
+BWD_BYTES_PER_ELEM = 6   # bf16: read g + read x + write gx
+
+
+# ----------------------------------------------------------------------------------------------
+# timing harness (device-agnostic so the N>1 aggregation is testable with gloo on CPU)
+# ----------------------------------------------------------------------------------------------
+def timed_region(step, steps, warmup, sync, dist_mod=None):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier+sync on both sides.
+    Returns the max-over-ranks wall time in seconds."""
+    for i in range(warmup):
+        step(i)
+    sync()
+    if dist_mod is not None:
+        dist_mod.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    sync()
+    if dist_mod is not None:
+        dist_mod.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist_mod is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        if dist_mod.get_backend() == "nccl":
+            t = t.cuda()
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def aggregate_value(elems_per_rank_step, steps, world, seconds):
+    """whole-job throughput in Gelem/s: all ranks' elements / max-over-ranks time"""
+    return elems_per_rank_step * steps * world / seconds / 1e9
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU workload
+# ----------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, device, rows=ROWS, cols=COLS, nsets=4, seed=1234):
+        import torch
+        import llm_qat_amd
+        from llm_qat_amd import _lib
+        _lib.lib()  # no fallback: raises if the HIP library is absent
+        self.torch, self.ops = torch, llm_qat_amd.ops
+        self.rows, self.cols, self.nsets = rows, cols, nsets
+        self.n = rows * cols
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.sets = []
+        for _ in range(nsets):
+            w = (torch.randn(rows, cols, generator=g, device=device) * 0.02).bfloat16()          # N(0, 0.02^2)
+            a = torch.randn(rows, cols, generator=g, device=device)
+            a[torch.rand(rows, cols, generator=g, device=device) < 1e-3] *= 20.0                  # outlier channels
+            a = a.bfloat16()
+            gw = (torch.randn(rows, cols, generator=g, device=device) * 1e-3).bfloat16()
+            ga = (torch.randn(rows, cols, generator=g, device=device) * 1e-3).bfloat16()
+            self.sets.append(dict(w=w, a=a, gw=gw, ga=ga, yw=torch.empty_like(w), ya=torch.empty_like(a),
+                                  gxw=torch.empty_like(w), gxa=torch.empty_like(a),
+                                  bw=torch.empty(rows, 2, device=device), ba=torch.empty(rows, 2, device=device)))
+        L = _lib.lib()
+        self.L, self._lib = L, _lib
+        self.stream = torch.cuda.current_stream(device).cuda_stream
+
+    # raw C-ABI launches on preallocated buffers (what the autograd Functions do, minus the allocator)
+    def fwd(self, s, leg):
+        x, y, b, bits = (s["w"], s["yw"], s["bw"], 4) if leg == "w" else (s["a"], s["ya"], s["ba"], 8)
+        rc = self.L.fq_sym_fwd(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16,
+                               self._lib.SEM_CPU_EAGER, b.data_ptr(), None, 0, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_sym_fwd")
+
+    def bwd(self, s, leg):
+        g, x, gx, b = (s["gw"], s["w"], s["gxw"], s["bw"]) if leg == "w" else (s["ga"], s["a"], s["gxa"], s["ba"])
+        rc = self.L.fq_ste_bwd_rows(g.data_ptr(), x.data_ptr(), gx.data_ptr(), self.rows, self.cols, -2.0, 2.0,
+                                    b.data_ptr(), self._lib.DTYPE_BF16, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_ste_bwd_rows")
+
+    def step(self, i):
+        # forward on set i, backward on the set whose forward ran two steps ago: between the forward
+        # and the backward of one tensor > 1.4 GB of other traffic passes, as in a real training step
+        sf = self.sets[i % self.nsets]
+        sb = self.sets[(i + self.nsets - 2) % self.nsets]
+        self.fwd(sf, "w")
+        self.fwd(sf, "a")
+        self.bwd(sb, "a")
+        self.bwd(sb, "w")
+
+    def prime_bounds(self):
+        for s in self.sets:
+            self.fwd(s, "w")
+            self.fwd(s, "a")
+        self.torch.cuda.synchronize()
+
+    def time_kernel(self, fn, iters):
+        """average launch duration (ms) of one kernel kind, HIP events on the launch stream, rotating buffers"""
+        torch = self.torch
+        for i in range(3):
+            fn(self.sets[i % self.nsets])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fn(self.sets[i % self.nsets])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+
+def roofline_entry(name, bytes_per_launch, ms, traffic=None):
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(ms * 1e3, 2),
+            "algorithmic_bytes_per_launch": bytes_per_launch}
+
+
+def load_traffic():
+    """HBM bytes per launch from committed rocprofv3 --pmc runs (profiles/traffic.json), if present."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return {}
+    return {}
+
+
+def cpu_baseline(budget_s=15.0):
+    """The reference's CPU path on this host: eager op chain on the full W4 + A8 step, repeated for ~budget_s."""
+    import torch
+    from oracle import eager_chain as E
+    g = torch.Generator().manual_seed(1234)
+    w = (torch.randn(ROWS, COLS, generator=g) * 0.02).bfloat16()
+    a = torch.randn(ROWS, COLS, generator=g)
+    a[torch.rand(ROWS, COLS, generator=g) < 1e-3] *= 20.0
+    a = a.bfloat16()
+    gw = (torch.randn(ROWS, COLS, generator=g) * 1e-3).bfloat16()
+    clip = torch.tensor([-2.0, 2.0])
+    times = []
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        E.sym_forward(w, 4)
+        E.ste_backward(gw, w, clip)
+        E.sym_forward(a, 8)
+        E.ste_backward(gw, a, clip)
+        times.append(time.perf_counter() - t0)
+        if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 50:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    cores = torch.get_num_threads()
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(2 * ROWS * COLS / best / 1e9, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
+            "sample": f"full step (W4 + A8 fwd+bwd on [4096,11008] bf16), {len(times)} repeats, best of all but the first; "
+                      f"eager ATen op chain restating models/utils_quant.py (bit-equal to the reference on CPU)",
+            "host_cpu": model, "host_logical_cpus": os.cpu_count(), "seconds_best": round(best, 4)}
+
+
+def gpu_eager(wl, iters=5):
+    """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd)."""
+    import torch
+    from oracle import eager_chain as E
+    clip = torch.tensor([-2.0, 2.0])
+    s = wl.sets[0]
+
+    def one(k):
+        s = wl.sets[k % wl.nsets]
+        E.sym_forward(s["w"], 4)
+        E.ste_backward(s["gw"], s["w"], clip)
+        E.sym_forward(s["a"], 8)
+        E.ste_backward(s["ga"], s["a"], clip)
+
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(iters):
+        one(k + 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(2 * wl.n / dt / 1e9, 2), "unit": "Gelem/s", "ms_per_step": round(dt * 1e3, 3),
+            "what": "oracle/eager_chain.py (the reference's op chain) on the same tensors, same GPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip per-kernel / eager measurements")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")  # RCCL; used for the timing barrier / max only -- no data-path collective
+    elif args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE unset); running 1 rank",
+              file=sys.stderr)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    wl = Workload(device)
+    wl.prime_bounds()
+    seconds = timed_region(wl.step, args.steps, args.warmup, torch.cuda.synchronize, dist)
+    elems_step = 2 * wl.n
+    value = aggregate_value(elems_step, args.steps, world, seconds)
+    ms_step = seconds / args.steps * 1e3
+    algo_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_BYTES_PER_ELEM)
+
+    out = {
+        "metric": "fake-quant fwd+bwd Gelem/s, 4096x11008 bf16 W4A8",
+        "value": round(value, 2), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "SymQuantizer fwd + STE bwd, W4 on weight-style [4096,11008] + A8 on activation-style "
+                               "[4096,11008], bf16, clip [-2,2] (LLaMA-7B W4-A8 down_proj shapes, configs[1])",
+                   "elements_per_step": elems_step, "buffer_sets": wl.nsets, "parallelism": "replicas" if world > 1 else "1gpu",
+                   "semantics": "cpu_eager"},
+        "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
+    }
+
+    if rank == 0 and not args.no_extras:
+        traffic = load_traffic()
+        it = max(20, min(args.steps, 200))
+        nb = wl.n
+        ks = {
+            "sym_fwd_w4": (lambda s: wl.fwd(s, "w"), nb * FWD_BYTES_PER_ELEM),
+            "sym_fwd_a8": (lambda s: wl.fwd(s, "a"), nb * FWD_BYTES_PER_ELEM),
+            "ste_bwd_a8": (lambda s: wl.bwd(s, "a"), nb * BWD_BYTES_PER_ELEM),
+            "ste_bwd_w4": (lambda s: wl.bwd(s, "w"), nb * BWD_BYTES_PER_ELEM),
+        }
+        kernels = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ks.items()]
+        out["kernels"] = kernels
+        dom = max(kernels, key=lambda e: e["us_per_launch"])
+        out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        out["roofline"]["kernel"] = dom["kernel"]
+        tot_us = sum(e["us_per_launch"] for e in kernels)
+        out["roofline_step"] = {"bound": "hbm", "achieved": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "what": "all four kernels of one step: 10 algorithmic B/elem / sum of launch times"}
+        if world == 1:
+            out["gpu_eager"] = gpu_eager(wl)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

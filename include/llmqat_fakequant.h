@@ -1,0 +1,122 @@
+/*
+ * llmqat_fakequant.h -- C ABI of the MI355X (gfx950) fake-quantization kernel library.
+ *
+ * This is the drop-in boundary for LLM-QAT's fake-quant hot path.  The reference has no
+ * native layer: its "kernels" are chains of eager ATen ops inside two
+ * torch.autograd.Functions.  Each entry point below replaces one of those chains; the
+ * reference lines are cited per function (paths relative to the LLM-QAT repo root).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / HIP types in signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - every pointer is DEVICE memory owned by the caller (PyTorch's caching allocator);
+ *     the library never allocates, frees or retains a pointer, and never synchronises.
+ *     All work is enqueued on `stream`, so every call is hipGraph-capturable.
+ *   - tensors are contiguous; a "row" is the unit that shares one scale:
+ *         ndim <= 3 : rows = numel / shape[-1], cols = shape[-1]    (utils_quant.py:53-59)
+ *         ndim == 4 : rows = d0*d1, cols = d2*d3                    (utils_quant.py:60-68)
+ *         layerwise : rows = 1, cols = numel                        (utils_quant.py:50-51)
+ *   - return value: 0 on success, negative FQ_ERR_* otherwise; fq_last_error() gives a
+ *     thread-local message.  Nothing throws across the boundary.
+ *   - stateless and re-entrant: safe from the autograd thread, under
+ *     torch.utils.checkpoint recompute and inside DDP/FSDP hooks.
+ *   - arithmetic: bit-exact replay of the reference's op-by-op rounding in the tensor
+ *     dtype (see DESIGN.md "Numerics"); `sem` picks how Python scalars met the tensor.
+ */
+#ifndef LLMQAT_FAKEQUANT_H
+#define LLMQAT_FAKEQUANT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQ_ABI_VERSION 1
+
+/* element types */
+#define FQ_DTYPE_F32 0
+#define FQ_DTYPE_BF16 1
+#define FQ_DTYPE_F16 2
+
+/* scalar semantics (only differ for bf16/fp16 rows with |max| < ~4e-5, and Asym fp32 `.div(S)`) */
+#define FQ_SEM_CPU_EAGER 0    /* canonical: what ATen's CPU kernels do; pinned by tests/golden */
+#define FQ_SEM_DEVICE_EAGER 1 /* what ATen's GPU kernels do (fp32 "opmath" scalars, div-by-scalar = mul by 1/S) */
+
+/* error codes */
+#define FQ_OK 0
+#define FQ_ERR_DTYPE (-1)
+#define FQ_ERR_BITS (-2)
+#define FQ_ERR_SHAPE (-3)
+#define FQ_ERR_NULL (-4)
+#define FQ_ERR_WORKSPACE (-5)
+#define FQ_ERR_LAUNCH (-6)
+#define FQ_ERR_ARG (-7)
+
+int fq_version(void);               /* == FQ_ABI_VERSION */
+const char* fq_build_info(void);    /* e.g. "llmqat_fakequant abi 1, gfx950, hip 7.2" */
+const char* fq_last_error(void);    /* thread-local; "" if the last call on this thread succeeded */
+
+/*
+ * Bytes of scratch the row-wise forwards need for this shape (0 for rows that fit the
+ * single-pass register-resident kernels; 8 bytes per row for the two-pass path that very
+ * long rows -- e.g. layerwise -- take).  The caller allocates it; contents are don't-care.
+ */
+size_t fq_rowwise_workspace_bytes(int64_t rows, int64_t cols, int dtype);
+
+/*
+ * SymQuantizer.forward -- models/utils_quant.py:37-74
+ *   m = max|x| per row; s = reciprocal(m + 1e-6) * (2^(bits-1)-1); y = round(x*s) / (s + 1e-6)
+ * Replaces 9 ATen kernels (abs, max, add, reciprocal, mul, mul, round, add, div) by one pass:
+ * x is read once, y written once.  No clamp (the reference has none): 8-bit bf16 bins reach +-128.
+ *   x, y      [rows, cols] dtype, contiguous; y may not alias x
+ *   bits      2..31 (the callers use 3..16)
+ *   row_bounds_out  optional float[rows][2] = {+m, -m}: bounds of the row's values, which
+ *             fq_ste_bwd_rows can use to skip re-reading x (pass NULL if unused)
+ */
+int fq_sym_fwd(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem,
+               float* row_bounds_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * AsymQuantizer.forward -- models/utils_quant.py:96-149
+ *   beta = min x, alpha = max x - min x per row; n = (x-beta)/(alpha+1e-8);
+ *   y = round(n*(2^bits-1)) / (2^bits-1) * (alpha+1e-8) + beta
+ * Replaces ~13 ATen kernels (incl. the duplicated min-reduce :119/:124).
+ *   row_bounds_out  optional float[rows][2] = {max, min}
+ */
+int fq_asym_fwd(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem,
+                float* row_bounds_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Test/diagnostic variants: same arithmetic, additionally emit the integer bin index of
+ * every element (int32; NaN -> INT32_MIN, +-Inf -> +-INT32_MAX) and the per-row scale
+ * terms as fp32:  Sym: scale_out[rows] = s ;  Asym: scale_out[rows][2] = {alpha, beta}.
+ * Any of idx_out / scale_out may be NULL.
+ */
+int fq_sym_fwd_debug(const void* x, void* y, int32_t* idx_out, float* scale_out, int64_t rows, int64_t cols,
+                     int bits, int dtype, int sem, void* workspace, size_t workspace_bytes, void* stream);
+int fq_asym_fwd_debug(const void* x, void* y, int32_t* idx_out, float* scale_out, int64_t rows, int64_t cols,
+                      int bits, int dtype, int sem, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * SymQuantizer.backward / AsymQuantizer.backward (identical) -- models/utils_quant.py:77-87, :152-162
+ *   gx = g.clone(); gx[x >= hi] = 0; gx[x <= lo] = 0        (NaN x passes g)
+ * Replaces 5 ATen kernels (clone, ge, index_put_, le, index_put_).  lo/hi are first rounded to
+ * the tensor dtype, as the reference's comparison does.  g, x, gx: n elements of `dtype`.
+ */
+int fq_ste_bwd(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, int dtype, void* stream);
+
+/*
+ * Same result as fq_ste_bwd on a [rows, cols] tensor, but consults the per-row bounds a
+ * forward call recorded: rows whose bounds lie strictly inside (lo, hi) cannot be masked,
+ * so their x is not re-read (gx = g: 4 instead of 6 bytes/element for bf16).  Rows with
+ * NaN/out-of-range bounds take the normal path.  row_bounds must describe the same x.
+ */
+int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi,
+                    const float* row_bounds, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLMQAT_FAKEQUANT_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of the C ABI in include/llmqat_fakequant.h.
+
+There is no fallback: if the HIP library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libllmqat_fakequant.so")
+ABI_VERSION = 1
+
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+SEM_CPU_EAGER, SEM_DEVICE_EAGER = 0, 1
+
+# every symbol include/llmqat_fakequant.h declares (tests check the .so exports them all)
+EXPORTS = (
+    "fq_version", "fq_build_info", "fq_last_error", "fq_rowwise_workspace_bytes",
+    "fq_sym_fwd", "fq_asym_fwd", "fq_sym_fwd_debug", "fq_asym_fwd_debug",
+    "fq_ste_bwd", "fq_ste_bwd_rows",
+)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class FakeQuantLibraryError(RuntimeError):
+    pass
+
+
+def _bind(L):
+    vp, i64, i32, f32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.fq_version.argtypes = []
+    L.fq_version.restype = i32
+    L.fq_build_info.argtypes = []
+    L.fq_build_info.restype = ctypes.c_char_p
+    L.fq_last_error.argtypes = []
+    L.fq_last_error.restype = ctypes.c_char_p
+    L.fq_rowwise_workspace_bytes.argtypes = [i64, i64, i32]
+    L.fq_rowwise_workspace_bytes.restype = sz
+    for name in ("fq_sym_fwd", "fq_asym_fwd"):
+        f = getattr(L, name)
+        f.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, sz, vp]
+        f.restype = i32
+    for name in ("fq_sym_fwd_debug", "fq_asym_fwd_debug"):
+        f = getattr(L, name)
+        f.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, sz, vp]
+        f.restype = i32
+    L.fq_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32, i32, vp]
+    L.fq_ste_bwd.restype = i32
+    L.fq_ste_bwd_rows.argtypes = [vp, vp, vp, i64, i64, f32, f32, vp, i32, vp]
+    L.fq_ste_bwd_rows.restype = i32
+    return L
+
+
+def lib():
+    """The loaded library; raises FakeQuantLibraryError (never falls back) if unavailable."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise FakeQuantLibraryError(
+                        f"{LIB_PATH} not found: build it with `python llm-qat_amd/build.py` "
+                        "(or __graft_entry__.build()). There is no CPU/eager fallback.")
+                try:
+                    L = ctypes.CDLL(LIB_PATH)
+                except OSError as e:  # e.g. libamdhip64 missing
+                    raise FakeQuantLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+                _bind(L)
+                v = L.fq_version()
+                if v != ABI_VERSION:
+                    raise FakeQuantLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+                _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().fq_last_error().decode(errors="replace")
+        if rc in (-2,):  # FQ_ERR_BITS
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

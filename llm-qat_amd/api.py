@@ -1,0 +1,9 @@
+"""Public surface of the package."""
+from . import ops
+from ._lib import FakeQuantLibraryError
+from .ops import get_semantics, set_semantics
+from .utils_quant import AsymQuantizer, QuantizeLinear, SymQuantizer
+
+__version__ = "0.1.0"
+__all__ = ["SymQuantizer", "AsymQuantizer", "QuantizeLinear", "ops", "set_semantics", "get_semantics",
+           "FakeQuantLibraryError"]

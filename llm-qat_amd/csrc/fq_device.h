@@ -1,0 +1,295 @@
+// fq_device.h -- device-side building blocks of the gfx950 fake-quant kernels.
+//
+// Written for CDNA4 only: 64-lane wavefronts, DPP row operations + v_readlane for the
+// wave-level reductions, v_cvt_pk_bf16_f32 for bf16 rounding, v_pk_max_u16 for the packed
+// |x| max.  No portability layer.
+//
+// Numerics contract (DESIGN.md "Numerics"): the reference computes every intermediate in
+// the tensor dtype, one rounding per ATen op.  Every helper that is named after a
+// reference op therefore ends in a round-to-dtype; the build uses -ffp-contract=off so
+// no mul/add pair is ever fused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fq {
+
+enum : int { F32 = 0, BF16 = 1, F16 = 2 };
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ------------------------------------------------------------------------------------
+// dtype traits.  A "dword" is the 32-bit register unit: 1 fp32 element or 2 16-bit ones.
+// ------------------------------------------------------------------------------------
+template <int DT> struct Ty;
+
+template <> struct Ty<F32> {
+    static constexpr int ESIZE = 4, EPD = 1;
+    static constexpr uint32_t ABS_MASK = 0x7FFFFFFFu;
+    __device__ static __forceinline__ void unpack(uint32_t w, float (&f)[1]) { f[0] = as_f(w); }
+    __device__ static __forceinline__ uint32_t pack(const float (&f)[1]) { return as_u(f[0]); }
+    __device__ static __forceinline__ void round_dt(float (&)[1]) {}
+    __device__ static __forceinline__ float rb(float v) { return v; }
+    // packed |x| max on raw bits (sign-magnitude order; NaN patterns sort above Inf, so the
+    // integer max propagates NaN exactly like torch.max)
+    __device__ static __forceinline__ uint32_t absmax_acc(uint32_t acc, uint32_t w) {
+        uint32_t a = w & ABS_MASK;
+        return acc > a ? acc : a;
+    }
+    __device__ static __forceinline__ uint32_t absmax_finish(uint32_t acc) { return acc; }  // -> fp32 bits of max|x|
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+};
+
+template <> struct Ty<BF16> {
+    static constexpr int ESIZE = 2, EPD = 2;
+    static constexpr uint32_t ABS_MASK = 0x7FFF7FFFu;
+    __device__ static __forceinline__ void unpack(uint32_t w, float (&f)[2]) {
+        f[0] = as_f(w << 16);
+        f[1] = as_f(w & 0xFFFF0000u);
+    }
+    __device__ static __forceinline__ uint32_t pack(const float (&f)[2]) {  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        f32x2_t v;
+        v.x = f[0];
+        v.y = f[1];
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    }
+    __device__ static __forceinline__ void round_dt(float (&f)[2]) { unpack(pack(f), f); }
+    __device__ static __forceinline__ float rb(float v) { return (float)(__bf16)v; }
+    __device__ static __forceinline__ uint32_t absmax_acc(uint32_t acc, uint32_t w) {  // v_and + v_pk_max_u16
+        u16x2_t a = __builtin_bit_cast(u16x2_t, acc), b = __builtin_bit_cast(u16x2_t, w & ABS_MASK);
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));
+    }
+    __device__ static __forceinline__ uint32_t absmax_finish(uint32_t acc) {
+        uint32_t lo = acc & 0xFFFFu, hi = acc >> 16;
+        return (lo > hi ? lo : hi) << 16;
+    }
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) { return as_f((uint32_t)((const uint16_t*)p)[i] << 16); }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
+        ((uint16_t*)p)[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+};
+
+template <> struct Ty<F16> {
+    static constexpr int ESIZE = 2, EPD = 2;
+    static constexpr uint32_t ABS_MASK = 0x7FFF7FFFu;
+    __device__ static __forceinline__ void unpack(uint32_t w, float (&f)[2]) {
+        f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+        f[0] = (float)h.x;
+        f[1] = (float)h.y;
+    }
+    __device__ static __forceinline__ uint32_t pack(const float (&f)[2]) {  // 2x v_cvt_f16_f32 (RNE) + pack
+        f16x2_t h;
+        h.x = (_Float16)f[0];
+        h.y = (_Float16)f[1];
+        return __builtin_bit_cast(uint32_t, h);
+    }
+    __device__ static __forceinline__ void round_dt(float (&f)[2]) { unpack(pack(f), f); }
+    __device__ static __forceinline__ float rb(float v) { return (float)(_Float16)v; }
+    __device__ static __forceinline__ uint32_t absmax_acc(uint32_t acc, uint32_t w) { return Ty<BF16>::absmax_acc(acc, w); }
+    __device__ static __forceinline__ uint32_t absmax_finish(uint32_t acc) {
+        uint32_t lo = acc & 0xFFFFu, hi = acc >> 16;
+        uint16_t m = (uint16_t)(lo > hi ? lo : hi);
+        return as_u((float)__builtin_bit_cast(_Float16, m));
+    }
+    __device__ static __forceinline__ float load1(const void* p, int64_t i) {
+        return (float)__builtin_bit_cast(_Float16, ((const uint16_t*)p)[i]);
+    }
+    __device__ static __forceinline__ void store1(void* p, int64_t i, float v) {
+        ((uint16_t*)p)[i] = __builtin_bit_cast(uint16_t, (_Float16)v);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// order-preserving float <-> uint key (for atomicMax-based cross-block min/max)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t okey(float v) {
+    uint32_t u = as_u(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float okey_inv(uint32_t k) { return as_f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// ------------------------------------------------------------------------------------
+// wave64 reduction for IDEMPOTENT ops (max / min): 4 DPP steps make every 16-lane row
+// uniform, 4 v_readlane + scalar ops finish.  All 64 lanes must be active.
+// ------------------------------------------------------------------------------------
+struct OpMaxU {
+    __device__ static __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a > b ? a : b; }
+};
+struct OpMaxF {  // v_max_f32: ignores NaN operands; NaN is tracked separately by the callers
+    __device__ static __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return as_u(__builtin_fmaxf(as_f(a), as_f(b))); }
+};
+struct OpMinF {
+    __device__ static __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return as_u(__builtin_fminf(as_f(a), as_f(b))); }
+};
+
+template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+template <class Op> __device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
+    v = Op::f(v, dpp<0xB1>(v));   // quad_perm:[1,0,3,2]
+    v = Op::f(v, dpp<0x4E>(v));   // quad_perm:[2,3,0,1]
+    v = Op::f(v, dpp<0x141>(v));  // row_half_mirror
+    v = Op::f(v, dpp<0x140>(v));  // row_mirror  -> each 16-lane row uniform
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return Op::f(Op::f(a, b), Op::f(c, d));
+}
+
+// block reduction over NW waves through LDS (one barrier); result uniform in every thread
+template <class Op, int NW> __device__ __forceinline__ uint32_t block_reduce(uint32_t v, uint32_t* lds /*[NW]*/) {
+    uint32_t w = wave_reduce<Op>(v);
+    if constexpr (NW == 1) return w;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = w;
+    __syncthreads();
+    uint32_t r = lds[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = Op::f(r, lds[i]);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+// per-row scale terms
+// ------------------------------------------------------------------------------------
+struct SymConst {   // launch-uniform
+    float qmax;     // 2^(bits-1)-1 as fp32 (ATen keeps a Python scalar in fp32 for mul)
+    float c6;       // the "+1e-6": rounded to the dtype (CPU-eager) or plain fp32 (device-eager)
+};
+struct SymRow {
+    float s, t2, rinv;
+};
+// utils_quant.py:71-72:  s = reciprocal(max + 1e-6) * qmax ;  divisor = s + 1e-6
+template <int DT> __device__ __forceinline__ SymRow sym_row(float m, SymConst k) {
+    using T = Ty<DT>;
+    SymRow r;
+    const float t1 = T::rb(m + k.c6);
+    const float rc = T::rb(1.0f / t1);  // IEEE divide
+    r.s = T::rb(rc * k.qmax);
+    r.t2 = T::rb(r.s + k.c6);
+    r.rinv = 1.0f / r.t2;  // only used by the bf16 FAST path (exactness argument: DESIGN.md)
+    return r;
+}
+
+struct AsymConst {
+    float S;      // 2^bits - 1 as fp32
+    float invS;   // fp32 1/S   (device-eager: x.div(python_scalar) == x * (1/S))
+    float c8;     // the "+1e-8"
+    int mul_inv;  // 1 -> use invS
+};
+struct AsymRow {
+    float mn, al, a;
+};
+// utils_quant.py:116-124,:144: alpha = max - min ; beta = min ; a = alpha + 1e-8
+template <int DT> __device__ __forceinline__ AsymRow asym_row(float mx, float mn, AsymConst k) {
+    using T = Ty<DT>;
+    AsymRow r;
+    r.mn = mn;
+    r.al = T::rb(mx - mn);
+    r.a = T::rb(r.al + k.c8);
+    return r;
+}
+
+__device__ __forceinline__ int32_t idx_i32(float q) {  // same coding as the oracle / fixtures
+    if (q != q) return INT32_MIN;
+    if (q >= 2.0e9f) return __builtin_isinf(q) ? INT32_MAX : 2000000000;
+    if (q <= -2.0e9f) return __builtin_isinf(q) ? -INT32_MAX : -2000000000;
+    return (int32_t)q;
+}
+
+// ------------------------------------------------------------------------------------
+// element chains on one dword.  `idx` (if non-null) receives EPD bin indices.
+// ------------------------------------------------------------------------------------
+// utils_quant.py:72   output = round(input * s).div(s + 1e-6)
+template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_dword(uint32_t w, const SymRow& r, int32_t* idx) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(w, f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * r.s;
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = __builtin_rintf(f[e]);  // v_rndne_f32
+    if (idx) {
+#pragma unroll
+        for (int e = 0; e < T::EPD; ++e) idx[e] = idx_i32(f[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = FAST ? f[e] * r.rinv : f[e] / r.t2;
+    return T::pack(f);
+}
+
+// utils_quant.py:144-147
+template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(w, f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] - r.mn;  // input - beta
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] / r.a;  // / (alpha + 1e-8)
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * k.S;  // * s
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = __builtin_rintf(f[e]);
+    if (idx) {
+#pragma unroll
+        for (int e = 0; e < T::EPD; ++e) idx[e] = idx_i32(f[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = k.mul_inv ? f[e] * k.invS : f[e] / k.S;  // .div(s)
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * r.a;  // * (alpha + 1e-8)
+    T::round_dt(f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] + r.mn;  // + beta
+    return T::pack(f);
+}
+
+// min/max/NaN accumulation for Asym on one dword
+struct MinMax {
+    float mx, mn;
+    uint32_t absacc;  // packed |x| max: only consulted for "is there a NaN"
+};
+template <int DT> __device__ __forceinline__ void minmax_acc(MinMax& a, uint32_t w) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(w, f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) {
+        a.mx = __builtin_fmaxf(a.mx, f[e]);
+        a.mn = __builtin_fminf(a.mn, f[e]);
+    }
+    a.absacc = T::absmax_acc(a.absacc, w);
+}
+__device__ __forceinline__ bool absbits_is_nan(uint32_t fp32_abs_bits) { return fp32_abs_bits > 0x7F800000u; }
+
+// STE mask on one dword (utils_quant.py:85-86): zero where x >= hi or x <= lo; NaN x passes
+template <int DT> __device__ __forceinline__ uint32_t ste_dword(uint32_t g, uint32_t x, float lo, float hi) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(x, f);
+    if constexpr (T::EPD == 1) {
+        return (f[0] >= hi || f[0] <= lo) ? 0u : g;
+    } else {
+        uint32_t keep = 0;
+        if (!(f[0] >= hi || f[0] <= lo)) keep |= 0x0000FFFFu;
+        if (!(f[1] >= hi || f[1] <= lo)) keep |= 0xFFFF0000u;
+        return g & keep;
+    }
+}
+
+}  // namespace fq

@@ -1,0 +1,514 @@
+// fq_kernels.h -- the gfx950 kernels of the fake-quant hot path.
+//
+//   row_reg_kernel      one row per wave (TPR=64) or per workgroup (TPR=256/1024); the whole row
+//                       is loaded ONCE with 16-byte global loads and stays in VGPRs across the
+//                       reduce -> scale -> round -> dequant sequence.  HBM traffic = read x + write y.
+//   row_generic_kernel  any alignment / odd widths: element loads, two sweeps (2nd sweep is L2-hot).
+//   stats / apply       two-pass path for rows too long for registers (layerwise = one row).
+//   ste_kernel          straight-through-estimator mask, pure streaming.
+//   ste_rows_kernel     same, but skips the x read for rows whose recorded bounds lie inside the clip.
+//
+// Roofline for all of them: HBM bandwidth (<= ~10 VALU ops per element, no MFMA).
+#pragma once
+#include "fq_device.h"
+
+namespace fq {
+
+struct RowArgs {
+    const void* x;
+    void* y;
+    int32_t* idx;    // optional (debug): bin index per element
+    float* scale;    // optional (debug): Sym s[rows] / Asym {alpha,beta}[rows]
+    float* bounds;   // optional: {upper, lower} bound of the row's values, for ste_rows_kernel
+    int64_t rows;
+    int64_t cols;
+    SymConst sym;
+    AsymConst asym;
+};
+
+// ------------------------------------------------------------------------------------
+// Register-resident row kernel.
+//   nvec = cols / elements-per-16B must satisfy nvec <= TPR * VPT.
+//   Thread t owns vectors t, t+TPR, ...: each wave-instruction reads 1 KiB contiguous.
+//   Out-of-range slots re-load the row's last vector (idempotent for max/min), so no load
+//   sits behind a branch; only stores are predicated.
+// ------------------------------------------------------------------------------------
+template <int DT, int TPR, int VPT, bool ASYM, bool FAST>
+__global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    constexpr int NW = TPR / 64;
+    __shared__ uint32_t red[3][NW > 1 ? NW : 1];
+
+    int64_t row;
+    int t;
+    if constexpr (TPR == 64) {
+        row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        t = threadIdx.x & 63;
+        if (row >= a.rows) return;  // wave-uniform
+    } else {
+        row = blockIdx.x;
+        t = threadIdx.x;
+    }
+    const int nvec = (int)(a.cols / EPV);
+    const uint4* __restrict__ xr = (const uint4*)((const char*)a.x + row * a.cols * T::ESIZE);
+    uint4* __restrict__ yr = (uint4*)((char*)a.y + row * a.cols * T::ESIZE);
+
+    uint4 r[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        int v = t + i * TPR;
+        v = v < nvec ? v : nvec - 1;
+        r[i] = xr[v];
+    }
+
+    SymRow sr;
+    AsymRow ar;
+    if constexpr (!ASYM) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            acc = T::absmax_acc(acc, r[i].x);
+            acc = T::absmax_acc(acc, r[i].y);
+            acc = T::absmax_acc(acc, r[i].z);
+            acc = T::absmax_acc(acc, r[i].w);
+        }
+        const uint32_t mbits = block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]);
+        const float m = as_f(mbits);
+        sr = sym_row<DT>(m, a.sym);
+        if (t == 0) {
+            if (a.scale) a.scale[row] = sr.s;
+            if (a.bounds) {
+                a.bounds[2 * row] = m;
+                a.bounds[2 * row + 1] = -m;
+            }
+        }
+    } else {
+        MinMax mm;
+        {
+            float f0[T::EPD];
+            T::unpack(r[0].x, f0);
+            mm.mx = mm.mn = f0[0];
+            mm.absacc = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            minmax_acc<DT>(mm, r[i].x);
+            minmax_acc<DT>(mm, r[i].y);
+            minmax_acc<DT>(mm, r[i].z);
+            minmax_acc<DT>(mm, r[i].w);
+        }
+        const uint32_t nb = block_reduce<OpMaxU, NW>(T::absmax_finish(mm.absacc), red[0]);
+        float mx = as_f(block_reduce<OpMaxF, NW>(as_u(mm.mx), red[1]));
+        float mn = as_f(block_reduce<OpMinF, NW>(as_u(mm.mn), red[2]));
+        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
+        ar = asym_row<DT>(mx, mn, a.asym);
+        if (t == 0) {
+            if (a.scale) {
+                a.scale[2 * row] = ar.al;
+                a.scale[2 * row + 1] = ar.mn;
+            }
+            if (a.bounds) {
+                a.bounds[2 * row] = mx;
+                a.bounds[2 * row + 1] = mn;
+            }
+        }
+    }
+
+    int32_t* idxr = a.idx ? a.idx + row * a.cols : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = t + i * TPR;
+        uint4 o;
+        int32_t ib[EPV];
+        if constexpr (!ASYM) {
+            o.x = sym_dword<DT, FAST>(r[i].x, sr, idxr ? ib + 0 * T::EPD : nullptr);
+            o.y = sym_dword<DT, FAST>(r[i].y, sr, idxr ? ib + 1 * T::EPD : nullptr);
+            o.z = sym_dword<DT, FAST>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
+            o.w = sym_dword<DT, FAST>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
+        } else {
+            o.x = asym_dword<DT>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
+            o.y = asym_dword<DT>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
+            o.z = asym_dword<DT>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
+            o.w = asym_dword<DT>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
+        }
+        if (v < nvec) {
+            yr[v] = o;
+            if (idxr) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) idxr[(int64_t)v * EPV + e] = ib[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// scalar element chains (generic / two-pass-unaligned paths)
+// ------------------------------------------------------------------------------------
+template <int DT, bool FAST> __device__ __forceinline__ float sym_elem(float x, const SymRow& r, int32_t* idx) {
+    using T = Ty<DT>;
+    float q = __builtin_rintf(T::rb(x * r.s));
+    if (idx) *idx = idx_i32(q);
+    return FAST ? q * r.rinv : q / r.t2;  // stored through T::store1 -> rounded to dtype
+}
+template <int DT> __device__ __forceinline__ float asym_elem(float x, const AsymRow& r, const AsymConst& k, int32_t* idx) {
+    using T = Ty<DT>;
+    float n = T::rb(T::rb(x - r.mn) / r.a);
+    float q = __builtin_rintf(T::rb(n * k.S));
+    if (idx) *idx = idx_i32(q);
+    float w = T::rb(k.mul_inv ? q * k.invS : q / k.S);
+    return T::rb(w * r.a) + r.mn;
+}
+
+// Any width / alignment; TPR threads sweep the row twice.
+template <int DT, int TPR, bool ASYM>
+__global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowArgs a) {
+    using T = Ty<DT>;
+    constexpr int NW = TPR / 64;
+    __shared__ uint32_t red[3][NW > 1 ? NW : 1];
+    int64_t row;
+    int t;
+    if constexpr (TPR == 64) {
+        row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        t = threadIdx.x & 63;
+        if (row >= a.rows) return;
+    } else {
+        row = blockIdx.x;
+        t = threadIdx.x;
+    }
+    const int64_t base = row * a.cols;
+    const int64_t cols = a.cols;
+    const float first = T::load1(a.x, base);  // cols >= 1 guaranteed by the host
+    SymRow sr;
+    AsymRow ar;
+    if constexpr (!ASYM) {
+        uint32_t acc = 0;
+        for (int64_t c = t; c < cols; c += TPR) {
+            uint32_t b = as_u(T::load1(a.x, base + c)) & 0x7FFFFFFFu;
+            acc = acc > b ? acc : b;
+        }
+        const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
+        sr = sym_row<DT>(m, a.sym);
+        if (t == 0) {
+            if (a.scale) a.scale[row] = sr.s;
+            if (a.bounds) {
+                a.bounds[2 * row] = m;
+                a.bounds[2 * row + 1] = -m;
+            }
+        }
+    } else {
+        float mx = first, mn = first;
+        uint32_t acc = 0;
+        for (int64_t c = t; c < cols; c += TPR) {
+            float v = T::load1(a.x, base + c);
+            mx = __builtin_fmaxf(mx, v);
+            mn = __builtin_fminf(mn, v);
+            uint32_t b = as_u(v) & 0x7FFFFFFFu;
+            acc = acc > b ? acc : b;
+        }
+        const uint32_t nb = block_reduce<OpMaxU, NW>(acc, red[0]);
+        mx = as_f(block_reduce<OpMaxF, NW>(as_u(mx), red[1]));
+        mn = as_f(block_reduce<OpMinF, NW>(as_u(mn), red[2]));
+        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);
+        ar = asym_row<DT>(mx, mn, a.asym);
+        if (t == 0) {
+            if (a.scale) {
+                a.scale[2 * row] = ar.al;
+                a.scale[2 * row + 1] = ar.mn;
+            }
+            if (a.bounds) {
+                a.bounds[2 * row] = mx;
+                a.bounds[2 * row + 1] = mn;
+            }
+        }
+    }
+    for (int64_t c = t; c < cols; c += TPR) {
+        const float v = T::load1(a.x, base + c);
+        int32_t* ip = a.idx ? a.idx + base + c : nullptr;
+        float o;
+        if constexpr (!ASYM) o = sym_elem<DT, false>(v, sr, ip);
+        else o = asym_elem<DT>(v, ar, a.asym, ip);
+        T::store1(a.y, base + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Two-pass path: pass 1 reduces fixed-size chunks and merges them with atomicMax on
+// order-preserving keys (ws[row] = {max key, ~min key}, zero-initialised by the host with
+// hipMemsetAsync); pass 2 applies.  Sym uses ws[2*row] = fp32 bits of max|x|.
+// ------------------------------------------------------------------------------------
+constexpr int TP_THREADS = 256;
+constexpr int TP_VPT = 4;                              // 16-byte vectors per thread per chunk (VEC path)
+constexpr int TP_EPT = 16;                             // elements per thread per chunk (scalar path)
+
+template <int DT, bool VEC> __host__ __device__ constexpr int tp_chunk_elems() {
+    return VEC ? TP_THREADS * TP_VPT * (16 / Ty<DT>::ESIZE) : TP_THREADS * TP_EPT;
+}
+
+template <int DT, bool ASYM, bool VEC>
+__global__ __launch_bounds__(TP_THREADS) void stats_kernel(RowArgs a, uint32_t* __restrict__ ws, int64_t chunks) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    constexpr int CH = tp_chunk_elems<DT, VEC>();
+    __shared__ uint32_t red[3][TP_THREADS / 64];
+    const int64_t row = blockIdx.x / chunks;
+    const int64_t c0 = (blockIdx.x % chunks) * CH;
+    const int64_t base = row * a.cols;
+    const int t = threadIdx.x;
+    int64_t cend = c0 + CH;
+    if (cend > a.cols) cend = a.cols;
+    uint32_t acc = 0;
+    float mx, mn;
+    if constexpr (VEC) {
+        const uint4* xr = (const uint4*)((const char*)a.x + (base + c0) * T::ESIZE);
+        const int nvec = (int)((cend - c0) / EPV);  // >= 1
+        uint4 r[TP_VPT];
+#pragma unroll
+        for (int i = 0; i < TP_VPT; ++i) {
+            int v = t + i * TP_THREADS;
+            v = v < nvec ? v : nvec - 1;
+            r[i] = xr[v];
+        }
+        if constexpr (!ASYM) {
+#pragma unroll
+            for (int i = 0; i < TP_VPT; ++i) {
+                acc = T::absmax_acc(acc, r[i].x);
+                acc = T::absmax_acc(acc, r[i].y);
+                acc = T::absmax_acc(acc, r[i].z);
+                acc = T::absmax_acc(acc, r[i].w);
+            }
+            acc = T::absmax_finish(acc);
+        } else {
+            MinMax mm;
+            float f0[T::EPD];
+            T::unpack(r[0].x, f0);
+            mm.mx = mm.mn = f0[0];
+            mm.absacc = 0;
+#pragma unroll
+            for (int i = 0; i < TP_VPT; ++i) {
+                minmax_acc<DT>(mm, r[i].x);
+                minmax_acc<DT>(mm, r[i].y);
+                minmax_acc<DT>(mm, r[i].z);
+                minmax_acc<DT>(mm, r[i].w);
+            }
+            acc = T::absmax_finish(mm.absacc);
+            mx = mm.mx;
+            mn = mm.mn;
+        }
+    } else {
+        mx = mn = T::load1(a.x, base + c0);
+        for (int64_t c = c0 + t; c < cend; c += TP_THREADS) {
+            float v = T::load1(a.x, base + c);
+            uint32_t b = as_u(v) & 0x7FFFFFFFu;
+            acc = acc > b ? acc : b;
+            if constexpr (ASYM) {
+                mx = __builtin_fmaxf(mx, v);
+                mn = __builtin_fminf(mn, v);
+            }
+        }
+    }
+    acc = block_reduce<OpMaxU, TP_THREADS / 64>(acc, red[0]);
+    if constexpr (!ASYM) {
+        if (t == 0) atomicMax(&ws[2 * row], acc);
+    } else {
+        mx = as_f(block_reduce<OpMaxF, TP_THREADS / 64>(as_u(mx), red[1]));
+        mn = as_f(block_reduce<OpMinF, TP_THREADS / 64>(as_u(mn), red[2]));
+        if (t == 0) {
+            const bool nan = absbits_is_nan(acc);
+            atomicMax(&ws[2 * row], nan ? 0xFFFFFFFFu : okey(mx));
+            atomicMax(&ws[2 * row + 1], nan ? 0xFFFFFFFFu : ~okey(mn));
+        }
+    }
+}
+
+template <int DT, bool ASYM, bool FAST, bool VEC>
+__global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint32_t* __restrict__ ws, int64_t chunks) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    constexpr int CH = tp_chunk_elems<DT, VEC>();
+    const int64_t row = blockIdx.x / chunks;
+    const int64_t chunk = blockIdx.x % chunks;
+    const int64_t c0 = chunk * CH;
+    const int64_t base = row * a.cols;
+    const int t = threadIdx.x;
+    int64_t cend = c0 + CH;
+    if (cend > a.cols) cend = a.cols;
+
+    SymRow sr;
+    AsymRow ar;
+    if constexpr (!ASYM) {
+        const float m = as_f(ws[2 * row]);
+        sr = sym_row<DT>(m, a.sym);
+        if (chunk == 0 && t == 0) {
+            if (a.scale) a.scale[row] = sr.s;
+            if (a.bounds) {
+                a.bounds[2 * row] = m;
+                a.bounds[2 * row + 1] = -m;
+            }
+        }
+    } else {
+        const uint32_t k0 = ws[2 * row], k1 = ws[2 * row + 1];
+        float mx, mn;
+        if (k0 == 0xFFFFFFFFu || k1 == 0xFFFFFFFFu) mx = mn = as_f(0x7FC00000u);
+        else {
+            mx = okey_inv(k0);
+            mn = okey_inv(~k1);
+        }
+        ar = asym_row<DT>(mx, mn, a.asym);
+        if (chunk == 0 && t == 0) {
+            if (a.scale) {
+                a.scale[2 * row] = ar.al;
+                a.scale[2 * row + 1] = ar.mn;
+            }
+            if (a.bounds) {
+                a.bounds[2 * row] = mx;
+                a.bounds[2 * row + 1] = mn;
+            }
+        }
+    }
+
+    if constexpr (VEC) {
+        const uint4* xr = (const uint4*)((const char*)a.x + (base + c0) * T::ESIZE);
+        uint4* yr = (uint4*)((char*)a.y + (base + c0) * T::ESIZE);
+        int32_t* idxr = a.idx ? a.idx + base + c0 : nullptr;
+        const int nvec = (int)((cend - c0) / EPV);
+        uint4 r[TP_VPT];
+#pragma unroll
+        for (int i = 0; i < TP_VPT; ++i) {
+            int v = t + i * TP_THREADS;
+            v = v < nvec ? v : nvec - 1;
+            r[i] = xr[v];
+        }
+#pragma unroll
+        for (int i = 0; i < TP_VPT; ++i) {
+            const int v = t + i * TP_THREADS;
+            uint4 o;
+            int32_t ib[EPV];
+            if constexpr (!ASYM) {
+                o.x = sym_dword<DT, FAST>(r[i].x, sr, idxr ? ib + 0 * T::EPD : nullptr);
+                o.y = sym_dword<DT, FAST>(r[i].y, sr, idxr ? ib + 1 * T::EPD : nullptr);
+                o.z = sym_dword<DT, FAST>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
+                o.w = sym_dword<DT, FAST>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
+            } else {
+                o.x = asym_dword<DT>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
+                o.y = asym_dword<DT>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
+                o.z = asym_dword<DT>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
+                o.w = asym_dword<DT>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
+            }
+            if (v < nvec) {
+                yr[v] = o;
+                if (idxr) {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) idxr[(int64_t)v * EPV + e] = ib[e];
+                }
+            }
+        }
+    } else {
+        for (int64_t c = c0 + t; c < cend; c += TP_THREADS) {
+            const float v = T::load1(a.x, base + c);
+            int32_t* ip = a.idx ? a.idx + base + c : nullptr;
+            float o;
+            if constexpr (!ASYM) o = sym_elem<DT, FAST>(v, sr, ip);
+            else o = asym_elem<DT>(v, ar, a.asym, ip);
+            T::store1(a.y, base + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// STE backward (utils_quant.py:83-87).  VEC: n is a whole number of 16-byte vectors and all
+// three pointers are 16-byte aligned; each thread moves UNR vectors of g and of x.
+// ------------------------------------------------------------------------------------
+constexpr int STE_THREADS = 256;
+
+template <int DT, int UNR>
+__global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __restrict__ g, const uint4* __restrict__ x,
+                                                              uint4* __restrict__ gx, int64_t nvec, float lo, float hi) {
+    const int64_t v0 = (int64_t)blockIdx.x * (STE_THREADS * UNR) + threadIdx.x;
+    uint4 rg[UNR], rx[UNR];
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        int64_t v = v0 + (int64_t)i * STE_THREADS;
+        v = v < nvec ? v : nvec - 1;
+        rg[i] = g[v];
+        rx[i] = x[v];
+    }
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        const int64_t v = v0 + (int64_t)i * STE_THREADS;
+        uint4 o;
+        o.x = ste_dword<DT>(rg[i].x, rx[i].x, lo, hi);
+        o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
+        o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
+        o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
+        if (v < nvec) gx[v] = o;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(STE_THREADS) void ste_scalar_kernel(const void* __restrict__ g, const void* __restrict__ x,
+                                                                 void* __restrict__ gx, int64_t n, float lo, float hi) {
+    using T = Ty<DT>;
+    const int64_t stride = (int64_t)gridDim.x * STE_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * STE_THREADS + threadIdx.x; i < n; i += stride) {
+        const float v = T::load1(x, i);
+        const bool masked = (v >= hi) || (v <= lo);
+        if constexpr (T::ESIZE == 4) ((uint32_t*)gx)[i] = masked ? 0u : ((const uint32_t*)g)[i];
+        else ((uint16_t*)gx)[i] = masked ? (uint16_t)0 : ((const uint16_t*)g)[i];
+    }
+}
+
+// Row-aware STE: block b handles chunk (b % chunks) of row (b / chunks).  If the row's recorded
+// bounds are strictly inside (lo, hi) no element can be masked: copy g, never touch x.
+template <int DT, int UNR>
+__global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __restrict__ g, const void* __restrict__ x,
+                                                               void* __restrict__ gx, int64_t cols, int64_t chunks,
+                                                               const float* __restrict__ bounds, float lo, float hi) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const int64_t row = blockIdx.x / chunks;
+    const int64_t c0 = (blockIdx.x % chunks) * (STE_THREADS * UNR * EPV);
+    const int64_t off = (row * cols + c0) * T::ESIZE;
+    const uint4* gr = (const uint4*)((const char*)g + off);
+    const uint4* xr = (const uint4*)((const char*)x + off);
+    uint4* or_ = (uint4*)((char*)gx + off);
+    int64_t rem = cols - c0;
+    const int nvec = (int)((rem < (int64_t)STE_THREADS * UNR * EPV ? rem : (int64_t)STE_THREADS * UNR * EPV) / EPV);
+    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+    const bool safe = (ub < hi) && (lb > lo);  // false when a bound is NaN
+    const int t = threadIdx.x;
+    uint4 rg[UNR];
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        int v = t + i * STE_THREADS;
+        v = v < nvec ? v : nvec - 1;
+        rg[i] = gr[v];
+    }
+    if (safe) {  // block-uniform
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const int v = t + i * STE_THREADS;
+            if (v < nvec) or_[v] = rg[i];
+        }
+    } else {
+        uint4 rx[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            int v = t + i * STE_THREADS;
+            v = v < nvec ? v : nvec - 1;
+            rx[i] = xr[v];
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const int v = t + i * STE_THREADS;
+            uint4 o;
+            o.x = ste_dword<DT>(rg[i].x, rx[i].x, lo, hi);
+            o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
+            o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
+            o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
+            if (v < nvec) or_[v] = o;
+        }
+    }
+}
+
+}  // namespace fq

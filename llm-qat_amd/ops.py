@@ -1,0 +1,167 @@
+"""Functional front-end over the C ABI: torch tensors in, torch tensors out.
+
+Everything here is host-side plumbing (shape -> [rows, cols], dtype codes, stream handle,
+workspace); the arithmetic happens in the HIP kernels.  CPU tensors are rejected: this
+package is the MI355X path and has no CPU implementation.
+"""
+import os
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+_SEM_NAMES = {"cpu_eager": _lib.SEM_CPU_EAGER, "device_eager": _lib.SEM_DEVICE_EAGER}
+_semantics = _SEM_NAMES[os.environ.get("LLMQAT_AMD_SEMANTICS", "cpu_eager")]
+
+
+def set_semantics(name):
+    """'cpu_eager' (default; bit-equal to the reference run on CPU, pinned by fixtures) or
+    'device_eager' (bit-equal to the reference's eager ops run on the GPU).  They differ only for
+    bf16/fp16 rows whose |max| is below ~4e-5 and for fp32 AsymQuantizer (DESIGN.md "Numerics")."""
+    global _semantics
+    _semantics = _SEM_NAMES[name]
+
+
+def get_semantics():
+    return next(k for k, v in _SEM_NAMES.items() if v == _semantics)
+
+
+def rows_cols(shape, layerwise):
+    """Granularity rules of utils_quant.py:50-70 -> the [rows, cols] view the kernels take."""
+    n = 1
+    for d in shape:
+        n *= d
+    if layerwise:
+        return 1, n
+    nd = len(shape)
+    if nd <= 3:
+        cols = shape[-1] if nd else 1
+        return (n // cols if cols else 0), cols
+    if nd == 4:
+        return shape[0] * shape[1], shape[2] * shape[3]
+    raise ValueError(f"fake-quant expects at most 4 dimensions, got {nd}")  # utils_quant.py:70
+
+
+def _prep(x, what):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch.Tensor, got {type(x).__name__}")
+    if x.device.type != "cuda":
+        raise RuntimeError(f"{what}: tensor is on '{x.device}'. llm_qat_amd runs on MI355X only and has no CPU "
+                           "fallback; move the tensor to the GPU (or use the reference implementation on CPU).")
+    code = _DTYPES.get(x.dtype)
+    if code is None:
+        raise NotImplementedError(f"{what}: dtype {x.dtype} is not supported (float32, bfloat16, float16 are)")
+    return code
+
+
+class _DeviceOf:
+    """Make x's device current for the launch if it is not already."""
+
+    def __init__(self, x):
+        self.idx = x.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and self.idx != cur:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+def _stream(x):
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
+    what = f"{kind}_quantize"
+    code = _prep(x, what)
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    if x.numel() == 0:
+        if cols == 0 and not layerwise:
+            raise RuntimeError(f"{what}: cannot reduce over an empty last dimension")  # torch.max raises too
+        if layerwise:
+            raise RuntimeError(f"{what}: cannot reduce an empty tensor")
+        return torch.empty_like(x), None, None, None
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty_like(xc)
+    L = _lib.lib()
+    ws_bytes = L.fq_rowwise_workspace_bytes(rows, cols, code)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    ws_ptr = ws.data_ptr() if ws is not None else None
+    bounds = idx = scale = None
+    with _DeviceOf(x):
+        if debug:
+            idx = torch.empty(xc.shape, dtype=torch.int32, device=x.device)
+            scale = torch.empty((rows,) if kind == "sym" else (rows, 2), dtype=torch.float32, device=x.device)
+            fn = L.fq_sym_fwd_debug if kind == "sym" else L.fq_asym_fwd_debug
+            rc = fn(xc.data_ptr(), y.data_ptr(), idx.data_ptr(), scale.data_ptr(), rows, cols, int(num_bits), code,
+                    _semantics, ws_ptr, ws_bytes, _stream(x))
+        else:
+            if want_bounds:
+                bounds = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+            fn = L.fq_sym_fwd if kind == "sym" else L.fq_asym_fwd
+            rc = fn(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics,
+                    bounds.data_ptr() if bounds is not None else None, ws_ptr, ws_bytes, _stream(x))
+    _lib.check(rc, what)
+    if xc is not x:  # keep the input's strides, as the reference's elementwise ops do
+        out = torch.empty_like(x)
+        out.copy_(y)
+        y = out
+        if idx is not None:
+            idx = idx.reshape(x.shape)
+    return y, bounds, idx, scale
+
+
+def sym_quantize(x, num_bits, layerwise=False, want_bounds=False):
+    """SymQuantizer.forward (utils_quant.py:37-74).  -> y, or (y, row_bounds) if want_bounds."""
+    y, bounds, _, _ = _rowwise("sym", x, num_bits, layerwise, want_bounds, False)
+    return (y, bounds) if want_bounds else y
+
+
+def asym_quantize(x, num_bits, layerwise=False, want_bounds=False):
+    """AsymQuantizer.forward (utils_quant.py:96-149)."""
+    y, bounds, _, _ = _rowwise("asym", x, num_bits, layerwise, want_bounds, False)
+    return (y, bounds) if want_bounds else y
+
+
+def sym_quantize_debug(x, num_bits, layerwise=False):
+    """-> (y, idx int32, s float32[rows]) -- the bin indices the parity tests compare bit-exactly."""
+    y, _, idx, scale = _rowwise("sym", x, num_bits, layerwise, False, True)
+    return y, idx, scale
+
+
+def asym_quantize_debug(x, num_bits, layerwise=False):
+    """-> (y, idx int32, {alpha, beta} float32[rows, 2])"""
+    y, _, idx, scale = _rowwise("asym", x, num_bits, layerwise, False, True)
+    return y, idx, scale
+
+
+def ste_backward(grad_output, x, lo, hi, row_bounds=None, rows_cols_hint=None):
+    """STE mask (utils_quant.py:83-87): grad where lo < x < hi (or x is NaN), else 0."""
+    code = _prep(x, "ste_backward")
+    if grad_output.device != x.device:
+        raise RuntimeError("ste_backward: grad_output and input live on different devices")
+    if grad_output.shape != x.shape:
+        raise RuntimeError(f"ste_backward: shape mismatch {tuple(grad_output.shape)} vs {tuple(x.shape)}")
+    if grad_output.dtype != x.dtype:  # cannot happen through the autograd Functions (output dtype == input dtype)
+        raise NotImplementedError(f"ste_backward: grad dtype {grad_output.dtype} != input dtype {x.dtype}")
+    g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
+    xc = x if x.is_contiguous() else x.contiguous()
+    gx = torch.empty_like(g)
+    if g.numel() == 0:
+        return gx
+    L = _lib.lib()
+    with _DeviceOf(x):
+        if row_bounds is not None:
+            rows, cols = rows_cols_hint
+            rc = L.fq_ste_bwd_rows(g.data_ptr(), xc.data_ptr(), gx.data_ptr(), rows, cols, float(lo), float(hi),
+                                   row_bounds.data_ptr(), code, _stream(x))
+        else:
+            rc = L.fq_ste_bwd(g.data_ptr(), xc.data_ptr(), gx.data_ptr(), g.numel(), float(lo), float(hi), code, _stream(x))
+    _lib.check(rc, "ste_backward")
+    return gx

@@ -1,0 +1,89 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests are skipped (not failed) where no GPU is visible, e.g. in the build container."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    """One tests/golden/*.npz file: arrays + the JSON manifest written by make_golden.py."""
+
+    def __init__(self, fname):
+        self.z = np.load(os.path.join(GOLDEN, fname), allow_pickle=False)
+        doc = json.loads(bytes(self.z["manifest"]).decode())
+        self.meta = doc["meta"]
+        self.cases = doc["cases"]
+
+    def arr(self, case, key):
+        name = case["name"] if isinstance(case, dict) else case
+        return self.z[f"{name}/{key}"]
+
+
+_cache = {}
+
+
+def golden(fname):
+    if fname not in _cache:
+        _cache[fname] = Golden(fname)
+    return _cache[fname]
+
+
+# ---- bit-level helpers shared by the CPU and GPU tests -------------------------------------
+def nan_mask(a, dtype):
+    if dtype == "fp32":
+        return np.isnan(a)
+    if dtype == "bf16":
+        return (a & 0x7FFF) > 0x7F80
+    return (a & 0x7FFF) > 0x7C00
+
+
+def bits_equal(a, b, dtype):
+    """bit-for-bit equal, except that any NaN equals any NaN (payload/sign of NaN is not part of the contract)"""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    na, nb = nan_mask(a, dtype), nan_mask(b, dtype)
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    return bool((na == nb).all() and ((a == b) | (na & nb)).all())
+
+
+def mismatch_report(a, b, dtype, limit=5):
+    na, nb = nan_mask(a, dtype), nan_mask(b, dtype)
+    av, bv = (a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else (a, b)
+    bad = np.argwhere(~(((av == bv) | (na & nb)) & (na == nb)))
+    return f"{len(bad)} mismatches, first at {bad[:limit].tolist()}: got {[a[tuple(i)] for i in bad[:limit]]} want {[b[tuple(i)] for i in bad[:limit]]}"
+
+
+def to_f32(a, dtype):
+    """raw storage (uint16 bits / float32) -> float32 values"""
+    if dtype == "fp32":
+        return a.astype(np.float32)
+    if dtype == "bf16":
+        return (a.astype(np.uint32) << 16).view(np.float32)
+    return a.view(np.float16).astype(np.float32)

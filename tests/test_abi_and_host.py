@@ -1,0 +1,127 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/*.h declares; host-side logic
+(argument validation, shape -> [rows, cols] mapping, module surface) behaves like the reference's.
+No kernel is launched here."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    declared = header_symbols()
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fq_version() == _lib.ABI_VERSION
+    assert b"gfx950" in L.fq_build_info()
+
+
+def test_header_cites_reference_lines():
+    src = open(os.path.join(ROOT, "include", "llmqat_fakequant.h")).read()
+    for cite in ("utils_quant.py:37-74", "utils_quant.py:96-149", "utils_quant.py:77-87"):
+        assert cite in src
+
+
+def test_argument_validation_without_gpu():
+    """error codes come back before any HIP call; nothing throws across the boundary"""
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    assert L.fq_sym_fwd(None, None, 4, 4, 4, 9, 0, None, None, 0, None) == -1      # dtype
+    assert b"dtype" in L.fq_last_error()
+    assert L.fq_sym_fwd(None, None, 4, 4, 1, 1, 0, None, None, 0, None) == -2      # bits
+    assert L.fq_asym_fwd(None, None, 4, 4, 32, 1, 0, None, None, 0, None) == -2
+    assert L.fq_sym_fwd(None, None, 4, 4, 4, 1, 5, None, None, 0, None) == -7      # semantics
+    assert L.fq_sym_fwd(None, None, -1, 4, 4, 1, 0, None, None, 0, None) == -3     # shape
+    assert L.fq_sym_fwd(None, None, 4, 4, 4, 1, 0, None, None, 0, None) == -4      # null
+    assert L.fq_sym_fwd(None, None, 0, 4, 4, 1, 0, None, None, 0, None) == 0       # empty: ok, no launch
+    assert L.fq_last_error() == b""
+    assert L.fq_ste_bwd(None, None, None, 0, -2.0, 2.0, 1, None) == 0
+    assert L.fq_ste_bwd(None, None, None, 8, -2.0, 2.0, 1, None) == -4
+    assert L.fq_ste_bwd(None, None, None, 8, -2.0, 2.0, 3, None) == -1
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    assert L.fq_sym_fwd(p, p, 1, 8, 4, 1, 0, None, None, 0, None) == -7            # in-place rejected
+    with pytest.raises(ValueError):
+        _lib.check(-2, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(-6, "x")
+    assert L.fq_rowwise_workspace_bytes(4096, 11008, 1) == 0
+    assert L.fq_rowwise_workspace_bytes(1, 4096 * 11008, 1) == 8
+    assert L.fq_rowwise_workspace_bytes(3, 40000, 0) == 24
+
+
+def test_rows_cols_mapping_follows_reference_granularity():
+    from llm_qat_amd.ops import rows_cols
+    assert rows_cols((4096, 11008), False) == (4096, 11008)       # weight: per output channel
+    assert rows_cols((1, 2048, 4096), False) == (2048, 4096)      # activation / KV: per token
+    assert rows_cols((2, 3, 4, 5), False) == (6, 20)              # 4-D: per (d0, d1)   utils_quant.py:60-68
+    assert rows_cols((2, 3, 4, 5), True) == (1, 120)              # layerwise           utils_quant.py:50-51
+    assert rows_cols((9,), False) == (1, 9)
+    assert rows_cols((), False) == (1, 1)
+    with pytest.raises(ValueError):                               # utils_quant.py:70
+        rows_cols((1, 2, 3, 4, 5), False)
+    from oracle import oracle as O                                # the oracle maps shapes the same way
+    for shp in [(7,), (3, 5), (2, 3, 4), (2, 3, 4, 5)]:
+        for lw in (False, True):
+            assert tuple(rows_cols(shp, lw)) == tuple(O.rows_cols(shp, lw))
+
+
+def test_module_surface_matches_reference():
+    from llm_qat_amd.utils_quant import AsymQuantizer, QuantizeLinear, SymQuantizer
+    lin = QuantizeLinear(16, 8, bias=True, w_bits=4, a_bits=8)
+    assert lin.bias is None                                       # bias forced off  (:176)
+    assert list(lin.state_dict().keys()) == ["weight"]
+    assert (lin.w_bits, lin.a_bits, lin.act_layerwise, lin.weight_layerwise) == (4, 8, False, False)
+    assert lin.act_quantizer is SymQuantizer
+    assert QuantizeLinear(16, 8, symmetric=False, a_bits=8).act_quantizer is AsymQuantizer
+    assert not hasattr(QuantizeLinear(16, 8, a_bits=2), "act_quantizer")    # a_bits<=2 disables act quant (:184)
+    assert not hasattr(QuantizeLinear(16, 8, a_bits=32), "act_quantizer")
+    assert isinstance(lin, torch.nn.Linear)
+    for q in (SymQuantizer, AsymQuantizer):
+        assert issubclass(q, torch.autograd.Function)
+    # w_bits>=32 and a_bits>=32: plain linear, runs anywhere (no kernel involved)
+    plain = QuantizeLinear(16, 8)
+    x = torch.randn(3, 16)
+    torch.testing.assert_close(plain(x), torch.nn.functional.linear(x, plain.weight))
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    from llm_qat_amd.utils_quant import QuantizeLinear, SymQuantizer
+    with pytest.raises(RuntimeError, match="no CPU"):
+        SymQuantizer.apply(torch.randn(4, 8), torch.tensor([-2.0, 2.0]), 8, False)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        QuantizeLinear(8, 4, w_bits=4, a_bits=8)(torch.randn(2, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from llm_qat_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.FakeQuantLibraryError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under llm-qat_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "llm-qat_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle[/.]", r"libfq_oracle", r"\bfqo_"):
+                    assert not re.search(pat, src), (os.path.join(dirpath, f), pat)

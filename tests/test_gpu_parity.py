@@ -1,0 +1,325 @@
+"""GPU tier (-m gpu): the HIP kernels, called through the C ABI, against
+  (1) the golden vectors the real reference produced (tests/golden),
+  (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Bar: bin indices bit-exact; dequantized values bit-exact too (the north star allows 1e-6 rel;
+the tolerance used here is ZERO, except that any NaN equals any NaN); gradients bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal, golden, mismatch_report, to_f32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def dev_from(a, dtype):
+    if dtype == "fp32":
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).cuda().view(TD[dtype])
+
+
+def np_from(t):
+    t = t.detach().contiguous().cpu()
+    return t.numpy() if t.dtype in (torch.float32, torch.int32) else t.view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import llm_qat_amd
+    from llm_qat_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is absent
+    llm_qat_amd.set_semantics("cpu_eager")
+    return llm_qat_amd.ops
+
+
+# ------------------------------------------------------------------------------------------
+# (1) golden fixtures
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_forward_golden(ops, kind):
+    G = golden(f"{kind}_fwd.npz")
+    fn = ops.sym_quantize_debug if kind == "sym" else ops.asym_quantize_debug
+    failures = []
+    for c in G.cases:
+        dt = c["dtype"]
+        x = dev_from(G.arr(c, "x"), dt)
+        y, idx, scale = fn(x, c["bits"], c["layerwise"])
+        torch.cuda.synchronize()
+        y_np, idx_np = np_from(y), np_from(idx)
+        if not (idx_np == G.arr(c, "idx")).all():
+            failures.append(f"{c['name']}: idx {int((idx_np != G.arr(c, 'idx')).sum())} differ")
+        elif not bits_equal(y_np, G.arr(c, "y"), dt):
+            failures.append(f"{c['name']}: y {mismatch_report(y_np, G.arr(c, 'y'), dt)}")
+        if kind == "sym":
+            if not bits_equal(np_from(scale), to_f32(G.arr(c, "scale"), dt), "fp32"):
+                failures.append(f"{c['name']}: scale")
+        # the product entry point (no debug outputs) must give the same y
+        y2 = (ops.sym_quantize if kind == "sym" else ops.asym_quantize)(x, c["bits"], c["layerwise"])
+        if not bits_equal(np_from(y2), y_np, dt):
+            failures.append(f"{c['name']}: product path != debug path")
+    assert not failures, "\n".join(failures[:20])
+
+
+def test_ste_backward_golden(ops):
+    G = golden("ste_bwd.npz")
+    for c in G.cases:
+        dt = c["dtype"]
+        clip = G.arr(c, "clip")
+        gx = ops.ste_backward(dev_from(G.arr(c, "g"), dt), dev_from(G.arr(c, "x"), dt), float(clip[0]), float(clip[1]))
+        got, want = np_from(gx), G.arr(c, "gx")
+        a, b = (got.view(np.uint32), want.view(np.uint32)) if got.dtype == np.float32 else (got, want)
+        assert (a == b).all(), c["name"]
+
+
+def test_autograd_functions_golden(ops):
+    """SymQuantizer / AsymQuantizer .apply + .backward through autograd, CPU clip tensor as in the reference."""
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
+    G = golden("ste_bwd.npz")
+    for c in G.cases:
+        dt = c["dtype"]
+        quant = SymQuantizer if c["quant"] == "SymQuantizer" else AsymQuantizer
+        x = dev_from(G.arr(c, "x"), dt).requires_grad_(True)
+        y = quant.apply(x, torch.from_numpy(G.arr(c, "clip")), c["bits"], False)
+        assert y.dtype == x.dtype and y.shape == x.shape and y.device == x.device
+        y.backward(dev_from(G.arr(c, "g"), dt))
+        got, want = np_from(x.grad), G.arr(c, "gx")
+        a, b = (got.view(np.uint32), want.view(np.uint32)) if got.dtype == np.float32 else (got, want)
+        assert (a == b).all(), c["name"]
+
+
+def test_quantize_linear_golden(ops):
+    """QuantizeLinear drop-in: same ctor, state_dict == ['weight'], outputs/grads match the reference's.
+    The GEMM (F.linear) is rocBLAS on the device vs MKL on the CPU, so out/grads are compared with a
+    tolerance; the fake-quantized operands themselves are covered bit-exactly by the tests above."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    G = golden("quantize_linear.npz")
+    for c in G.cases:
+        dt = c["dtype"]
+        kw = {k: c[k] for k in ("w_bits", "a_bits", "symmetric", "act_layerwise", "weight_layerwise") if k in c}
+        lin = QuantizeLinear(c["in_features"], c["out_features"], bias=True, **kw)
+        assert lin.bias is None and list(lin.state_dict().keys()) == ["weight"]
+        lin = lin.cuda()
+        lin.weight.data = dev_from(G.arr(c, "w"), dt)
+        x = dev_from(G.arr(c, "x"), dt).requires_grad_(True)
+        out = lin(x)
+        out.backward(dev_from(G.arr(c, "go"), dt))
+        tol = dict(rtol=2e-2, atol=2e-2) if dt == "bf16" else dict(rtol=1e-4, atol=1e-5)
+        for name, got in (("out", out), ("gw", lin.weight.grad), ("gx", x.grad)):
+            want = torch.from_numpy(to_f32(G.arr(c, name), dt))
+            torch.testing.assert_close(got.float().cpu(), want, msg=lambda m: f"{c['name']} {name}: {m}", **tol)
+        # STE mask on the weight gradient is exact: weights beyond the clip get exactly zero
+        if 3 <= c["w_bits"] < 32:
+            gw = lin.weight.grad.float().cpu()
+            assert gw[3, 5] == 0 and gw[4, 6] == 0
+
+
+# ------------------------------------------------------------------------------------------
+# (2) seeded random inputs vs the CPU oracle
+# ------------------------------------------------------------------------------------------
+SHAPES = [(1, 8), (3, 16), (5, 24), (2, 40), (7, 256), (4, 264), (9, 512), (3, 520), (6, 1024), (2, 2048), (5, 2056),
+          (3, 4096), (2, 5120), (2, 11008), (2, 13824), (2, 16384), (1, 16392), (2, 32768), (1, 65536),
+          (3, 1), (4, 7), (5, 33), (3, 255), (2, 1001), (2, 4097), (1, 40000), (2, 40001)]
+
+
+def make_input(rng, shape, dtype, style):
+    if style == "weight":
+        x = rng.standard_normal(shape).astype(np.float32) * 0.02
+    elif style == "act":
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[rng.random(shape) < 1e-3] *= 20.0
+    else:  # mixed row scales
+        x = rng.standard_normal(shape).astype(np.float32) * rng.choice([1e-6, 1e-4, 0.02, 1.0, 50.0], size=(shape[0], 1)).astype(np.float32)
+    t = torch.from_numpy(x).to(TD[dtype])
+    return np_from(t), t.cuda()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_forward_vs_oracle(ops, kind, dtype):
+    rng = np.random.default_rng({"sym": 100, "asym": 200}[kind] + {"bf16": 1, "fp32": 2, "fp16": 3}[dtype])
+    fn = ops.sym_quantize_debug if kind == "sym" else ops.asym_quantize_debug
+    for shape in SHAPES:
+        for bits, style in ((4, "weight"), (8, "act"), (3, "mixed"), (16, "mixed")):
+            x_np, x = make_input(rng, shape, dtype, style)
+            y, idx, _ = fn(x, bits, False)
+            if kind == "sym":
+                yo, io, _ = O.sym_fwd(x_np, shape[0], shape[1], bits, dtype)
+            else:
+                yo, io, _, _ = O.asym_fwd(x_np, shape[0], shape[1], bits, dtype)
+            assert (np_from(idx) == io).all(), f"{kind} {dtype} {shape} b{bits}: idx"
+            assert bits_equal(np_from(y), yo, dtype), f"{kind} {dtype} {shape} b{bits}: {mismatch_report(np_from(y), yo, dtype)}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_layerwise_and_4d_vs_oracle(ops, kind, dtype):
+    """layerwise = one row (two-pass kernels once the tensor is long); 4-D = (d0*d1) rows."""
+    rng = np.random.default_rng(11)
+    fn = ops.sym_quantize_debug if kind == "sym" else ops.asym_quantize_debug
+    ofn = O.sym_fwd if kind == "sym" else O.asym_fwd
+    for shape in [(4, 50), (2, 3, 64), (64, 1024), (96, 4096), (3, 5, 7, 11), (2, 2, 16, 8), (33, 4001)]:
+        x_np, x = make_input(rng, shape, dtype, "act")
+        for layerwise in (True, False):
+            rows, cols = O.rows_cols(shape, layerwise)
+            y, idx, _ = fn(x, 8, layerwise)
+            res = ofn(x_np, rows, cols, 8, dtype)
+            assert (np_from(idx) == res[1]).all(), f"{kind} {dtype} {shape} lw={layerwise}"
+            assert bits_equal(np_from(y), res[0], dtype), f"{kind} {dtype} {shape} lw={layerwise}"
+    # NaN / Inf inside a long layerwise tensor (two-pass path): NaN poisons everything
+    x_np, x = make_input(rng, (64, 4096), dtype, "act")
+    x[17, 1234] = float("nan")
+    x_np = np_from(x)
+    y, idx, _ = fn(x, 8, True)
+    res = ofn(x_np, 1, 64 * 4096, 8, dtype)
+    assert (np_from(idx) == res[1]).all() and bits_equal(np_from(y), res[0], dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+def test_ste_vs_oracle(ops, dtype):
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 8, 64, 1000, 8192, 8200, 1 << 20, (1 << 20) + 3):
+        x_np, x = make_input(rng, (1, n), dtype, "act")
+        g_np, g = make_input(rng, (1, n), dtype, "weight")
+        for lo, hi in ((-2.0, 2.0), (-0.5, 0.75), (-0.3009, 0.3009)):
+            gx = ops.ste_backward(g, x, lo, hi)
+            want = O.ste_bwd(g_np, x_np, lo, hi, dtype)
+            assert bits_equal(np_from(gx), want, dtype), f"{dtype} n={n} clip=({lo},{hi})"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_ste_row_bounds_path_equals_plain(ops, dtype):
+    """fq_ste_bwd_rows (skips x for rows that cannot be clipped) == fq_ste_bwd == oracle."""
+    rng = np.random.default_rng(4)
+    for shape in [(64, 4096), (16, 11008), (5, 8200), (3, 264)]:
+        x_np, x = make_input(rng, shape, dtype, "mixed")   # some rows tiny (safe), some exceed the clip
+        x[1, 5] = float("nan")
+        x_np = np_from(x)
+        g_np, g = make_input(rng, shape, dtype, "weight")
+        for kind in ("sym", "asym"):
+            y, bounds = (ops.sym_quantize if kind == "sym" else ops.asym_quantize)(x, 8, False, want_bounds=True)
+            gx = ops.ste_backward(g, x, -2.0, 2.0, row_bounds=bounds, rows_cols_hint=shape)
+            want = O.ste_bwd(g_np, x_np, -2.0, 2.0, dtype)
+            assert bits_equal(np_from(gx), want, dtype), f"{kind} {dtype} {shape}"
+        b = bounds.cpu().numpy()
+        xf = to_f32(x_np, dtype)
+        ok = ~np.isnan(xf).any(axis=1)
+        assert (b[ok, 0] == xf[ok].max(axis=1)).all() and (b[ok, 1] == xf[ok].min(axis=1)).all()
+
+
+def test_non_contiguous_and_misaligned_inputs(ops):
+    rng = np.random.default_rng(8)
+    base = torch.from_numpy(rng.standard_normal((64, 48)).astype(np.float32)).cuda().bfloat16()
+    xt = base.t()                                   # non-contiguous
+    y = ops.sym_quantize(xt, 8, False)
+    assert y.stride() == xt.stride() and not y.is_contiguous()
+    want, _, _ = O.sym_fwd(np_from(xt), 48, 64, 8, "bf16")
+    assert bits_equal(np_from(y), want, "bf16")
+    flat = torch.from_numpy(rng.standard_normal(4096 * 3 + 1).astype(np.float32)).cuda().bfloat16()
+    xm = flat[1:].view(3, 4096)                     # contiguous but 2-byte aligned only
+    y = ops.sym_quantize(xm, 4, False)
+    want, _, _ = O.sym_fwd(np_from(xm), 3, 4096, 4, "bf16")
+    assert bits_equal(np_from(y), want, "bf16")
+    g = torch.ones_like(xm)
+    gx = ops.ste_backward(g, xm, -2.0, 2.0)
+    assert bits_equal(np_from(gx), O.ste_bwd(np_from(g), np_from(xm), -2.0, 2.0, "bf16"), "bf16")
+
+
+def test_error_behaviour_matches_reference(ops):
+    from llm_qat_amd.utils_quant import SymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    with pytest.raises(ValueError):      # utils_quant.py:70
+        SymQuantizer.apply(torch.zeros(1, 1, 1, 1, 2, device="cuda"), clip, 8, False)
+    SymQuantizer.apply(torch.zeros(1, 1, 1, 1, 2, device="cuda"), clip, 8, True)   # layerwise accepts any rank
+    with pytest.raises(RuntimeError):    # no CPU fallback
+        SymQuantizer.apply(torch.zeros(4, 4), clip, 8, False)
+    with pytest.raises(NotImplementedError):
+        SymQuantizer.apply(torch.zeros(4, 4, device="cuda", dtype=torch.float64), clip, 8, False)
+    e = SymQuantizer.apply(torch.zeros(0, 8, device="cuda"), clip, 8, False)
+    assert e.shape == (0, 8)
+
+
+# ------------------------------------------------------------------------------------------
+# (3) full-size properties (BASELINE.json sizes; the oracle checks a sample of rows)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,bits,style", [((4096, 11008), 4, "weight"), ((4096, 11008), 8, "act"),
+                                              ((2048, 4096), 8, "act"), ((2048, 11008), 8, "act"),
+                                              ((2048, 4096), 4, "act"), ((5120, 13824), 4, "weight")])
+def test_full_size_properties(ops, shape, bits, style):
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn(shape, generator=g, device="cuda", dtype=torch.float32)
+    if style == "weight":
+        x *= 0.02
+    else:
+        x[torch.rand(shape, generator=g, device="cuda") < 1e-3] *= 20.0
+    x = x.bfloat16()
+    y, idx, s = ops.sym_quantize_debug(x, bits, False)
+    qmax = 2 ** (bits - 1) - 1
+    # bins are integers within the representable range (+1 for the bf16 8-bit overshoot)
+    assert int(idx.abs().max()) <= qmax + 1
+    # every row attains the extreme bin (the row max maps to +-qmax or qmax+1)
+    assert bool((idx.abs().amax(dim=1) >= qmax).all())
+    # row-permutation equivariance: scales are per row, so permuting rows permutes outputs
+    perm = torch.randperm(shape[0], device="cuda", generator=g)
+    assert torch.equal(ops.sym_quantize(x[perm].contiguous(), bits, False), y[perm])
+    # within a row, element order is irrelevant to the scale
+    cperm = torch.randperm(shape[1], device="cuda", generator=g)
+    assert torch.equal(ops.sym_quantize(x[:, cperm].contiguous(), bits, False), y[:, cperm])
+    # bins are stable under re-quantization of the output: fq(fq(x)) has the same idx (scale grid is preserved)
+    # -- not guaranteed by the algebra in bf16, so only the weaker monotonicity is asserted:
+    xs = x[:64].float()
+    order = xs.argsort(dim=1)
+    assert bool((torch.gather(idx[:64], 1, order).diff(dim=1) >= 0).all())   # idx is monotone in x
+    # oracle on a sample of rows (first, last, and 30 random ones), bit-exact
+    rows = sorted(set([0, shape[0] - 1] + torch.randint(0, shape[0], (30,), generator=torch.Generator().manual_seed(1)).tolist()))
+    xs_np = np_from(x[rows])
+    yo, io, so = O.sym_fwd(xs_np, len(rows), shape[1], bits, "bf16")
+    assert (np_from(idx[rows]) == io).all()
+    assert bits_equal(np_from(y[rows]), yo, "bf16")
+    # backward at full size: mask property + checksum against torch.where
+    gg = (torch.randn(shape, generator=g, device="cuda") * 1e-3).bfloat16()
+    gx = ops.ste_backward(gg, x, -2.0, 2.0)
+    ref = torch.where((x >= 2.0) | (x <= -2.0), torch.zeros_like(gg), gg)
+    assert torch.equal(gx, ref)
+    _, bounds = ops.sym_quantize(x, bits, False, want_bounds=True)
+    gx2 = ops.ste_backward(gg, x, -2.0, 2.0, row_bounds=bounds, rows_cols_hint=shape)
+    assert torch.equal(gx2, ref)
+
+
+# ------------------------------------------------------------------------------------------
+# device-eager semantics: the kernels with sem=DEVICE_EAGER against LIVE ATen ops on this GPU
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+def test_device_eager_semantics_vs_live_aten(ops, dtype):
+    """What the reference's eager path computes ON THE DEVICE is given by running its op chain
+    (oracle/eager_chain.py) on the GPU.  With set_semantics('device_eager') the kernels must match
+    that bit for bit -- including rows with a tiny max, where CPU and device eager differ."""
+    import llm_qat_amd
+    from oracle import eager_chain as E
+    rng = np.random.default_rng(21)
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        bad = []
+        for shape in [(16, 256), (8, 4096), (4, 11008), (5, 33)]:
+            for style in ("mixed", "act"):
+                _, x = make_input(rng, shape, dtype, style)
+                for bits in (4, 8):
+                    y, idx, _ = ops.sym_quantize_debug(x, bits, False)
+                    ye, ie, _ = E.sym_forward(x, bits, False, want_idx=True)
+                    if not bits_equal(np_from(y), np_from(ye), dtype):
+                        bad.append(f"sym {dtype} {shape} {style} b{bits}: {mismatch_report(np_from(y), np_from(ye), dtype)}")
+                    y, idx, _ = ops.asym_quantize_debug(x, bits, False)
+                    ye = E.asym_forward(x, bits, False)
+                    if not bits_equal(np_from(y), np_from(ye), dtype):
+                        bad.append(f"asym {dtype} {shape} {style} b{bits}: {mismatch_report(np_from(y), np_from(ye), dtype)}")
+                gsrc = torch.randn(shape, device="cuda").to(TD[dtype])
+                gx = ops.ste_backward(gsrc, x, -2.0, 2.0)
+                if not torch.equal(gx, E.ste_backward(gsrc, x, torch.tensor([-2.0, 2.0]))):
+                    bad.append(f"ste {dtype} {shape}")
+        assert not bad, "\n".join(bad[:20])
+    finally:
+        llm_qat_amd.set_semantics("cpu_eager")

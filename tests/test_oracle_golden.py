@@ -1,0 +1,112 @@
+"""CPU tier: the oracle (oracle/fq_oracle.c) against the golden vectors the real reference produced.
+
+This is what pins the oracle: every forward / backward fixture must match bit for bit.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, golden, mismatch_report, to_f32
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_forward_matches_reference_fixtures(kind):
+    G = golden(f"{kind}_fwd.npz")
+    assert len(G.cases) >= 100
+    for c in G.cases:
+        x, dt = G.arr(c, "x"), c["dtype"]
+        rows, cols = O.rows_cols(c["shape"], c["layerwise"])
+        if kind == "sym":
+            y, idx, scale = O.sym_fwd(x, rows, cols, c["bits"], dt)
+            want_scale = to_f32(G.arr(c, "scale"), dt)
+            assert bits_equal(scale, want_scale, "fp32"), f"{c['name']}: scale"
+        else:
+            y, idx, alpha, beta = O.asym_fwd(x, rows, cols, c["bits"], dt)
+            assert bits_equal(alpha, to_f32(G.arr(c, "alpha"), dt), "fp32"), f"{c['name']}: alpha"
+            # beta may legitimately differ in the sign of zero (-0.0 vs +0.0 are equal minima)
+            wb = to_f32(G.arr(c, "beta"), dt)
+            assert bits_equal(np.where(beta == 0, 0.0, beta).astype(np.float32), np.where(wb == 0, 0.0, wb).astype(np.float32), "fp32"), f"{c['name']}: beta"
+        assert (idx == G.arr(c, "idx")).all(), f"{c['name']}: bin indices differ"
+        assert bits_equal(y, G.arr(c, "y"), dt), f"{c['name']}: {mismatch_report(y, G.arr(c, 'y'), dt)}"
+
+
+def test_ste_backward_matches_reference_fixtures():
+    G = golden("ste_bwd.npz")
+    assert len(G.cases) == 15
+    for c in G.cases:
+        clip = G.arr(c, "clip")
+        gx = O.ste_bwd(G.arr(c, "g"), G.arr(c, "x"), float(clip[0]), float(clip[1]), c["dtype"])
+        want = G.arr(c, "gx")
+        a, b = (gx.view(np.uint32), want.view(np.uint32)) if gx.dtype == np.float32 else (gx, want)
+        assert (a == b).all(), c["name"]  # a clone: even NaN payloads of g survive
+
+
+def test_no_clamp_8bit_bf16_reaches_128():
+    """the Sym forward has no clamp; in bf16 the 8-bit index reaches +-128."""
+    G = golden("sym_fwd.npz")
+    seen = 0
+    for c in G.cases:
+        if c["dtype"] == "bf16" and c["bits"] == 8 and not c.get("row_names"):
+            idx = G.arr(c, "idx")
+            finite = idx[np.abs(idx) < 10**6]
+            seen = max(seen, int(np.abs(finite).max()))
+    assert seen == 128
+
+
+def test_fixture_edge_rows():
+    """Edge behaviour pinned by the reference: zero rows, NaN rows, +Inf rows."""
+    G = golden("sym_fwd.npz")
+    c = next(c for c in G.cases if c["name"] == "sym_fp32_b4_adversarial")
+    names = c["row_names"]
+    y = G.arr(c, "y")
+    assert (y[names.index("all_zero")] == 0).all()
+    assert np.isnan(y[names.index("nan")]).all()                      # NaN anywhere -> whole row NaN
+    r = y[names.index("pos_inf")]
+    assert np.isnan(r[0]) and (r[1:] == 0).all()                      # NaN at the Inf, 0 elsewhere
+    A = golden("asym_fwd.npz")
+    c = next(c for c in A.cases if c["name"] == "asym_fp32_b4_adversarial")
+    assert np.isnan(A.arr(c, "y")[names.index("pos_inf")]).all()      # Asym: whole row NaN
+
+
+def test_oracle_rejects_bad_arguments():
+    x = np.zeros(4, np.float32)
+    with pytest.raises(ValueError):
+        O.sym_fwd(x, 1, 4, 40, "fp32")
+    with pytest.raises(TypeError):
+        O.sym_fwd(x, 1, 4, 4, "bf16")
+    with pytest.raises(ValueError):
+        O.rows_cols((1, 2, 3, 4, 5), False)
+
+
+def test_device_semantics_only_differ_where_documented():
+    """sem=1 (device eager) == sem=0 for fp32 Sym always, and for bf16 Sym unless the row max is tiny."""
+    rng = np.random.default_rng(5)
+    x32 = (rng.standard_normal((64, 96)) * rng.choice([1e-7, 1e-5, 1e-3, 1.0], size=(64, 1))).astype(np.float32)
+    y0, i0, _ = O.sym_fwd(x32, 64, 96, 8, "fp32", sem=O.SEM_CPU)
+    y1, i1, _ = O.sym_fwd(x32, 64, 96, 8, "fp32", sem=O.SEM_DEVICE)
+    assert (i0 == i1).all() and bits_equal(y0, y1, "fp32")
+    xb = (x32.view(np.uint32) >> 16).astype(np.uint16)
+    y0, i0, _ = O.sym_fwd(xb, 64, 96, 8, "bf16", sem=O.SEM_CPU)
+    y1, i1, _ = O.sym_fwd(xb, 64, 96, 8, "bf16", sem=O.SEM_DEVICE)
+    big = np.abs(to_f32(xb, "bf16")).max(axis=1) > 1e-3
+    assert (i0[big] == i1[big]).all() and bits_equal(y0[big], y1[big], "bf16")
+
+
+def test_bf16_reciprocal_multiply_equals_divide_exhaustively():
+    """The bf16 <=8-bit Sym kernel finishes with  y = rb(idx * (1/t2))  instead of  rb(idx / t2).
+    Exhaustive proof over every positive finite bf16 divisor and every |idx| <= 256 that the
+    two are bit-identical after the bf16 rounding (DESIGN.md "Numerics")."""
+    bits = np.arange(0x0080, 0x7F80, dtype=np.uint32)            # all positive normal bf16 values
+    t2 = (bits << 16).view(np.float32)
+    t2 = t2[(t2 > 1e-30) & (t2 < 1e30)]                          # t2 = s + 1e-6 lives in [1e-6, 1.3e8]
+    idx = np.arange(-256, 257, dtype=np.float32)
+
+    def rb(v):  # fp32 -> bf16 RNE (finite inputs)
+        u = v.view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    rinv = (np.float32(1.0) / t2).astype(np.float32)
+    for chunk in np.array_split(np.arange(t2.size), 64):
+        a = (idx[None, :] / t2[chunk, None]).astype(np.float32)
+        b = (idx[None, :] * rinv[chunk, None]).astype(np.float32)
+        assert (rb(a) == rb(b)).all()

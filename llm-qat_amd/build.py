@@ -13,11 +13,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libllmqat_fakequant.so")
-SOURCES = [os.path.join(CSRC, "fq_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "fq_kernels.h"), os.path.join(CSRC, "fq_device.h"),
-                  os.path.join(os.path.dirname(HERE), "include", "llmqat_fakequant.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fPIC", "-shared", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+SOURCES = [os.path.join(CSRC, f) for f in ("fq_api.hip", "fq_bf16.hip", "fq_f32.hip", "fq_f16.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fq_kernels.h", "fq_device.h", "fq_launch.h", "fq_dtype_impl.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "llmqat_fakequant.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+         "-fPIC", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
 def up_to_date():
@@ -30,10 +30,24 @@ def build_extension(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:  # one translation unit per element type: compile them side by side
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), obj, cmd))
+    objs = []
+    for p, obj, cmd in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB
 
 

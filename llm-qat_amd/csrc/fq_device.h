@@ -25,6 +25,29 @@ __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // ------------------------------------------------------------------------------------
+// 16-byte global accesses.  NT = non-temporal ("streaming") cache policy: every tensor on this
+// path is touched exactly once per launch, so lines need not be retained in L2 / Infinity Cache.
+// Measured on MI355X (tools/kbench): a 90 MB -> 90 MB copy runs 5.55 TB/s plain, 5.97 TB/s NT.
+// ------------------------------------------------------------------------------------
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const uint4* p) {
+    if constexpr (NT) {
+        u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT> __device__ __forceinline__ void st16(uint4* p, uint4 v) {
+    if constexpr (NT) {
+        u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, (u32x4_t*)p);
+    } else {
+        *p = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // dtype traits.  A "dword" is the 32-bit register unit: 1 fp32 element or 2 16-bit ones.
 // ------------------------------------------------------------------------------------
 template <int DT> struct Ty;

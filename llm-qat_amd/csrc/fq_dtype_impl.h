@@ -1,0 +1,138 @@
+// fq_dtype_impl.h -- kernel selection + launches for ONE element type (included by fq_<dtype>.hip).
+#pragma once
+#include "../../include/llmqat_fakequant.h"
+#include "fq_launch.h"
+
+namespace fq {
+
+#define FQ_LAUNCH(kern, grid, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, st, __VA_ARGS__)
+
+// Launch shape of the register-resident kernel, from tools/kbench on MI355X: 2-3 vectors per
+// thread is the sweet spot (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
+// 4096 cols: 256 x 2 = 6.1 us, 128 x 4 = 6.3, 64 x 8 = 6.9, 512 x 1 = 7.7).
+template <int DT, bool ASYM, bool FAST, bool NT>
+static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
+#define R(TPR, V)                                                                                                   \
+    case V:                                                                                                         \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NT, NT>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),        \
+                  (TPR == 64 ? 256 : TPR), st, a);                                                                  \
+        break;
+    if (nvec <= 192) {
+        switch ((int)((nvec + 63) / 64)) { R(64, 1) R(64, 2) R(64, 3) }
+    } else if (nvec <= 384) {
+        switch ((int)((nvec + 127) / 128)) { R(128, 2) R(128, 3) }
+    } else if (nvec <= 768) {
+        switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) }
+    } else if (nvec <= 4096) {
+        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+    } else {
+        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+    }
+#undef R
+}
+
+template <int DT, bool ASYM, bool FAST>
+static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0);
+    const int64_t nvec = a.cols / EPV;
+    const bool nt = a.rows * a.cols * T::ESIZE >= NT_MIN_BYTES;
+    bool two_pass = false, two_pass_vec = false;
+    if (vec_ok && nvec <= REG_MAX_VEC) {
+        if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
+        if (nt) launch_reg<DT, ASYM, FAST, true>(a, nvec, st);
+        else launch_reg<DT, ASYM, FAST, false>(a, nvec, st);
+    } else if (vec_ok) {
+        two_pass = two_pass_vec = true;
+    } else if (a.cols <= GENERIC_MAX_COLS) {
+        if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
+        if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, ASYM>), (a.rows + 3) / 4, 256, st, a);
+        else FQ_LAUNCH((row_generic_kernel<DT, 256, ASYM>), a.rows, 256, st, a);
+    } else {
+        two_pass = true;
+    }
+    if (two_pass) {
+        if (!ws || wsb < (size_t)a.rows * 8)
+            return fail(FQ_ERR_WORKSPACE, "two-pass path needs %zu workspace bytes, got %zu", (size_t)a.rows * 8, wsb);
+        const int64_t ch = two_pass_vec ? tp_chunk_elems<DT, true>() : tp_chunk_elems<DT, false>();
+        const int64_t chunks = (a.cols + ch - 1) / ch;
+        if (a.rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
+        if (hipMemsetAsync(ws, 0, (size_t)a.rows * 8, st) != hipSuccess) return fail(FQ_ERR_LAUNCH, "hipMemsetAsync failed");
+        uint32_t* w = (uint32_t*)ws;
+        if (two_pass_vec) {
+            FQ_LAUNCH((stats_kernel<DT, ASYM, true>), a.rows * chunks, TP_THREADS, st, a, w, chunks);
+            FQ_LAUNCH((apply_kernel<DT, ASYM, FAST, true>), a.rows * chunks, TP_THREADS, st, a, (const uint32_t*)w, chunks);
+        } else {
+            FQ_LAUNCH((stats_kernel<DT, ASYM, false>), a.rows * chunks, TP_THREADS, st, a, w, chunks);
+            FQ_LAUNCH((apply_kernel<DT, ASYM, FAST, false>), a.rows * chunks, TP_THREADS, st, a, (const uint32_t*)w, chunks);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return ok();
+}
+
+template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st) {
+    if (asym) return rowwise_t<DT, true, false>(a, ws, wsb, st);
+    if constexpr (DT == BF16) {
+        // bf16, Sym, <= 8 bits: the final divide becomes a multiply with the row's reciprocal --
+        // provably bit-identical after the bf16 rounding (DESIGN.md "Numerics").
+        if (fast) return rowwise_t<DT, false, true>(a, ws, wsb, st);
+    }
+    return rowwise_t<DT, false, false>(a, ws, wsb, st);
+}
+
+template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    if (aligned16(g) && aligned16(x) && aligned16(gx) && n % EPV == 0) {
+        const int64_t nvec = n / EPV;
+        const int64_t grid = (nvec + STE_THREADS - 1) / STE_THREADS;  // one vector per thread measured best (kbench)
+        if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "n too large");
+        if (n * T::ESIZE >= NT_MIN_BYTES)
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+        else
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, false>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+    } else {
+        int64_t grid = (n + STE_THREADS - 1) / STE_THREADS;
+        if (grid > 8192) grid = 8192;
+        FQ_LAUNCH((ste_scalar_kernel<DT>), grid, STE_THREADS, st, g, x, gx, n, lo, hi);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return ok();
+}
+
+template <int DT>
+int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
+                    hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0))
+        return launch_ste<DT>(g, x, gx, rows * cols, lo, hi, st);  // odd layout: plain path, same result
+    const int64_t nvec_row = cols / EPV;
+    // balanced chunks: every block of a row gets the same number of vectors (<= 256 x 8)
+    const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
+    const int cv = (int)((nvec_row + chunks - 1) / chunks);
+    const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
+    if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
+    const bool nt = rows * cols * T::ESIZE >= NT_MIN_BYTES;
+#define S(V)                                                                                                                       \
+    case V:                                                                                                                        \
+        if (nt) FQ_LAUNCH((ste_rows_kernel<DT, V, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);  \
+        else FQ_LAUNCH((ste_rows_kernel<DT, V, false>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);   \
+        break;
+    switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
+#undef S
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return ok();
+}
+
+#define FQ_INSTANTIATE(DT)                                                                                      \
+    template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
+    template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
+    template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t);
+
+}  // namespace fq

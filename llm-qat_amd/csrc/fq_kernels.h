@@ -33,7 +33,7 @@ struct RowArgs {
 //   Out-of-range slots re-load the row's last vector (idempotent for max/min), so no load
 //   sits behind a branch; only stores are predicated.
 // ------------------------------------------------------------------------------------
-template <int DT, int TPR, int VPT, bool ASYM, bool FAST>
+template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     for (int i = 0; i < VPT; ++i) {
         int v = t + i * TPR;
         v = v < nvec ? v : nvec - 1;
-        r[i] = xr[v];
+        r[i] = ld16<NTL>(&xr[v]);
     }
 
     SymRow sr;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             o.w = asym_dword<DT>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
         }
         if (v < nvec) {
-            yr[v] = o;
+            st16<NTS>(&yr[v], o);
             if (idxr) {
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) idxr[(int64_t)v * EPV + e] = ib[e];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
 // ------------------------------------------------------------------------------------
 constexpr int STE_THREADS = 256;
 
-template <int DT, int UNR>
+template <int DT, int UNR, bool NT = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __restrict__ g, const uint4* __restrict__ x,
                                                               uint4* __restrict__ gx, int64_t nvec, float lo, float hi) {
     const int64_t v0 = (int64_t)blockIdx.x * (STE_THREADS * UNR) + threadIdx.x;
@@ -430,8 +430,8 @@ __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __res
     for (int i = 0; i < UNR; ++i) {
         int64_t v = v0 + (int64_t)i * STE_THREADS;
         v = v < nvec ? v : nvec - 1;
-        rg[i] = g[v];
-        rx[i] = x[v];
+        rg[i] = ld16<NT>(&g[v]);
+        rx[i] = ld16<NT>(&x[v]);
     }
 #pragma unroll
     for (int i = 0; i < UNR; ++i) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __res
         o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
         o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
         o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
-        if (v < nvec) gx[v] = o;
+        if (v < nvec) st16<NT>(&gx[v], o);
     }
 }
 
@@ -458,55 +458,54 @@ __global__ __launch_bounds__(STE_THREADS) void ste_scalar_kernel(const void* __r
     }
 }
 
-// Row-aware STE: block b handles chunk (b % chunks) of row (b / chunks).  If the row's recorded
-// bounds are strictly inside (lo, hi) no element can be masked: copy g, never touch x.
-template <int DT, int UNR>
+// Row-aware STE: block b handles chunk (b % chunks) of row (b / chunks); a chunk is `cv` vectors
+// (cv <= STE_THREADS * VPT; the host balances chunks so no block is nearly empty).  If the row's
+// recorded bounds are strictly inside (lo, hi) no element can be masked: copy g, never touch x.
+template <int DT, int VPT, bool NT = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __restrict__ g, const void* __restrict__ x,
-                                                               void* __restrict__ gx, int64_t cols, int64_t chunks,
+                                                               void* __restrict__ gx, int64_t nvec_row, int64_t chunks, int cv,
                                                                const float* __restrict__ bounds, float lo, float hi) {
-    using T = Ty<DT>;
-    constexpr int EPV = 16 / T::ESIZE;
     const int64_t row = blockIdx.x / chunks;
-    const int64_t c0 = (blockIdx.x % chunks) * (STE_THREADS * UNR * EPV);
-    const int64_t off = (row * cols + c0) * T::ESIZE;
-    const uint4* gr = (const uint4*)((const char*)g + off);
-    const uint4* xr = (const uint4*)((const char*)x + off);
-    uint4* or_ = (uint4*)((char*)gx + off);
-    int64_t rem = cols - c0;
-    const int nvec = (int)((rem < (int64_t)STE_THREADS * UNR * EPV ? rem : (int64_t)STE_THREADS * UNR * EPV) / EPV);
+    const int64_t vs = (blockIdx.x % chunks) * cv;
+    const int64_t off = row * nvec_row + vs;
+    const uint4* gr = (const uint4*)g + off;
+    const uint4* xr = (const uint4*)x + off;
+    uint4* or_ = (uint4*)gx + off;
+    const int64_t rem = nvec_row - vs;
+    const int nvec = (int)(rem < cv ? rem : cv);
     const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
     const bool safe = (ub < hi) && (lb > lo);  // false when a bound is NaN
     const int t = threadIdx.x;
-    uint4 rg[UNR];
+    uint4 rg[VPT];
 #pragma unroll
-    for (int i = 0; i < UNR; ++i) {
+    for (int i = 0; i < VPT; ++i) {
         int v = t + i * STE_THREADS;
         v = v < nvec ? v : nvec - 1;
-        rg[i] = gr[v];
+        rg[i] = ld16<NT>(&gr[v]);
     }
     if (safe) {  // block-uniform
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) {
+        for (int i = 0; i < VPT; ++i) {
             const int v = t + i * STE_THREADS;
-            if (v < nvec) or_[v] = rg[i];
+            if (v < nvec) st16<NT>(&or_[v], rg[i]);
         }
     } else {
-        uint4 rx[UNR];
+        uint4 rx[VPT];
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) {
+        for (int i = 0; i < VPT; ++i) {
             int v = t + i * STE_THREADS;
             v = v < nvec ? v : nvec - 1;
-            rx[i] = xr[v];
+            rx[i] = ld16<NT>(&xr[v]);
         }
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) {
+        for (int i = 0; i < VPT; ++i) {
             const int v = t + i * STE_THREADS;
             uint4 o;
             o.x = ste_dword<DT>(rg[i].x, rx[i].x, lo, hi);
             o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
             o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
             o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
-            if (v < nvec) or_[v] = o;
+            if (v < nvec) st16<NT>(&or_[v], o);
         }
     }
 }

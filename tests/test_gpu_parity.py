@@ -261,8 +261,8 @@ def test_full_size_properties(ops, shape, bits, style):
     qmax = 2 ** (bits - 1) - 1
     # bins are integers within the representable range (+1 for the bf16 8-bit overshoot)
     assert int(idx.abs().max()) <= qmax + 1
-    # every row attains the extreme bin (the row max maps to +-qmax or qmax+1)
-    assert bool((idx.abs().amax(dim=1) >= qmax).all())
+    # every row reaches the top of the range (the row max maps to qmax-1 .. qmax+1: s is rounded in bf16)
+    assert bool((idx.abs().amax(dim=1) >= qmax - 1).all())
     # row-permutation equivariance: scales are per row, so permuting rows permutes outputs
     perm = torch.randperm(shape[0], device="cuda", generator=g)
     assert torch.equal(ops.sym_quantize(x[perm].contiguous(), bits, False), y[perm])

@@ -1,0 +1,241 @@
+// kbench.hip -- standalone tuning harness for the fake-quant kernels (not part of the product).
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I llm-qat_amd/csrc -o tools/kbench tools/kbench.hip
+//   ./tools/kbench [rows cols]
+//
+// Times kernel variants with HIP events on rotating buffer sets (defeats the 256 MiB Infinity
+// Cache) and prints achieved algorithmic GB/s.  Used to pick launch shapes; the winners are
+// moved into llm-qat_amd/csrc/fq_api.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "fq_kernels.h"
+
+using namespace fq;
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt(const uint4* p) {
+    u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt(uint4* p, uint4 v) {
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (u32x4*)p);
+}
+// ---------------------------------------------------------------- reference streaming kernels
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nvec) {
+    const int64_t v0 = (int64_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+    uint4 r[UNR];
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        int64_t v = v0 + (int64_t)i * 256;
+        v = v < nvec ? v : nvec - 1;
+        if constexpr (NT) r[i] = ld_nt(&in[v]);
+        else r[i] = in[v];
+    }
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        const int64_t v = v0 + (int64_t)i * 256;
+        if (v < nvec) {
+            if constexpr (NT) st_nt(&out[v], r[i]);
+            else out[v] = r[i];
+        }
+    }
+}
+
+// grid-stride copy: fixed grid, each block walks tiles
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void copy_gs_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nvec) {
+    const int64_t tile = 256 * UNR;
+    for (int64_t base = (int64_t)blockIdx.x * tile; base < nvec; base += (int64_t)gridDim.x * tile) {
+        uint4 r[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            int64_t v = base + threadIdx.x + (int64_t)i * 256;
+            v = v < nvec ? v : nvec - 1;
+            if constexpr (NT) r[i] = ld_nt(&in[v]);
+            else r[i] = in[v];
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const int64_t v = base + threadIdx.x + (int64_t)i * 256;
+            if (v < nvec) {
+                if constexpr (NT) st_nt(&out[v], r[i]);
+                else out[v] = r[i];
+            }
+        }
+    }
+}
+
+template <int UNR>
+__global__ __launch_bounds__(256) void read_kernel(const uint4* __restrict__ in, uint32_t* __restrict__ out, int64_t nvec) {
+    const int64_t v0 = (int64_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        int64_t v = v0 + (int64_t)i * 256;
+        v = v < nvec ? v : nvec - 1;
+        uint4 r = in[v];
+        acc |= r.x ^ r.y ^ r.z ^ r.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int UNR>
+__global__ __launch_bounds__(256) void write_kernel(uint4* __restrict__ out, int64_t nvec) {
+    const int64_t v0 = (int64_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        const int64_t v = v0 + (int64_t)i * 256;
+        if (v < nvec) out[v] = make_uint4((uint32_t)v, 1, 2, 3);
+    }
+}
+
+// ---------------------------------------------------------------- harness
+struct Bufs {
+    std::vector<void*> x, y, g, gx;
+    std::vector<float*> bounds;
+};
+
+static float time_it(const std::function<void(int)>& fn, int iters, int warm = 5) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) fn(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) fn(i);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0));
+    CK(hipEventDestroy(e1));
+    return ms / iters;
+}
+
+static void report(const char* name, double bytes, float ms) {
+    printf("%-44s %8.2f us  %8.1f GB/s  (%.1f%% of 8 TB/s)\n", name, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / 1e9 / 80.0);
+    fflush(stdout);
+}
+
+__global__ void fill_bf16(uint16_t* p, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        // sum of 4 bytes -> roughly bell shaped in [-2, 2] * scale
+        float v = ((float)(h & 255) + (float)((h >> 8) & 255) + (float)((h >> 16) & 255) + (float)(h >> 24) - 510.0f) / 255.0f;
+        p[i] = __builtin_bit_cast(uint16_t, (__bf16)(v * scale));
+    }
+}
+
+template <int TPR, int VPT, bool FAST, bool NTL, bool NTS>
+static void launch_sym(const void* x, void* y, float* bounds, int64_t rows, int64_t cols, int bits) {
+    RowArgs a{};
+    a.x = x; a.y = y; a.idx = nullptr; a.scale = nullptr; a.bounds = bounds; a.rows = rows; a.cols = cols;
+    a.sym.qmax = (float)((1 << (bits - 1)) - 1);
+    a.sym.c6 = 9.98377799987793e-07f;
+    const int64_t grid = TPR == 64 ? (rows + 3) / 4 : rows;
+    hipLaunchKernelGGL((row_reg_kernel<BF16, TPR, VPT, false, FAST, NTL, NTS>), dim3((unsigned)grid), dim3(TPR == 64 ? 256 : TPR), 0, 0, a);
+}
+
+int main(int argc, char** argv) {
+    const int64_t rows = argc > 2 ? atoll(argv[1]) : 4096, cols = argc > 2 ? atoll(argv[2]) : 11008;
+    const int64_t n = rows * cols;
+    const size_t bytes = (size_t)n * 2;
+    const int NS = 4, IT = 60;
+    Bufs b;
+    for (int s = 0; s < NS; ++s) {
+        void *x, *y, *g, *gx;
+        float* bd;
+        CK(hipMalloc(&x, bytes)); CK(hipMalloc(&y, bytes)); CK(hipMalloc(&g, bytes)); CK(hipMalloc(&gx, bytes));
+        CK(hipMalloc(&bd, rows * 2 * sizeof(float)));
+        hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint16_t*)x, n, 17u + s, 0.02f);
+        hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint16_t*)g, n, 99u + s, 0.001f);
+        b.x.push_back(x); b.y.push_back(y); b.g.push_back(g); b.gx.push_back(gx); b.bounds.push_back(bd);
+    }
+    CK(hipDeviceSynchronize());
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, %d CUs, clock %d MHz, mem clock %d MHz, bus %d bits | tensor %lld x %lld bf16 (%.1f MB)\n", prop.name,
+           prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.memoryBusWidth, (long long)rows,
+           (long long)cols, bytes / 1e6);
+    const int64_t nvec = n / 8;
+
+    // ---- ceilings
+#define COPY(U, NT)                                                                                                                 \
+    report("copy<UNR=" #U ",NT=" #NT ">", 2.0 * bytes, time_it([&](int i) {                                                        \
+               hipLaunchKernelGGL((copy_kernel<U, NT>), dim3((unsigned)((nvec + 256 * U - 1) / (256 * U))), dim3(256), 0, 0,       \
+                                  (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec);                                            \
+           }, IT));
+    COPY(1, false) COPY(2, false) COPY(4, false) COPY(8, false) COPY(4, true) COPY(8, true)
+#define COPYGS(U, NT, G)                                                                                                            \
+    report("copy_gs<UNR=" #U ",NT=" #NT ",grid=" #G ">", 2.0 * bytes, time_it([&](int i) {                                          \
+               hipLaunchKernelGGL((copy_gs_kernel<U, NT>), dim3(G), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec); \
+           }, IT));
+    COPYGS(4, false, 2048) COPYGS(4, false, 4096) COPYGS(8, false, 2048) COPYGS(4, true, 2048) COPYGS(2, false, 4096)
+    uint32_t* sink;
+    CK(hipMalloc(&sink, 64));
+    report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
+               hipLaunchKernelGGL((read_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);
+           }, IT));
+    report("read-only<UNR=8>", 1.0 * bytes, time_it([&](int i) {
+               hipLaunchKernelGGL((read_kernel<8>), dim3((unsigned)((nvec + 2047) / 2048)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);
+           }, IT));
+    report("write-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
+               hipLaunchKernelGGL((write_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (uint4*)b.y[i % NS], nvec);
+           }, IT));
+
+    // ---- sym forward variants (need cols/8 <= TPR*VPT)
+    const int64_t nv_row = cols / 8;
+#define SYM(TPR, VPT, FAST, NTL, NTS)                                                                                   \
+    if (nv_row <= (int64_t)TPR * VPT && nv_row > (int64_t)TPR * (VPT - 1))                                              \
+        report("sym_fwd<TPR=" #TPR ",VPT=" #VPT ",FAST=" #FAST ",NTL=" #NTL ",NTS=" #NTS ">", 2.0 * bytes,              \
+               time_it([&](int i) { launch_sym<TPR, VPT, FAST, NTL, NTS>(b.x[i % NS], b.y[i % NS], b.bounds[i % NS], rows, cols, 4); }, IT));
+    SYM(256, 6, true, false, false) SYM(256, 6, true, true, false) SYM(256, 6, true, false, true) SYM(256, 6, true, true, true)
+    SYM(512, 3, true, false, false) SYM(512, 3, true, true, true) SYM(1024, 2, true, true, true) SYM(256, 6, false, true, true)
+    SYM(256, 2, true, false, false) SYM(256, 2, true, true, true) SYM(128, 4, true, true, true) SYM(64, 8, true, true, true) SYM(512, 1, true, true, true)
+    SYM(256, 7, true, true, true) SYM(512, 4, true, true, true)
+
+    // ---- STE backward variants
+#define STE(U, NT)                                                                                                                  \
+    report("ste_vec<UNR=" #U ",NT=" #NT ">", 3.0 * bytes, time_it([&](int i) {                                                      \
+               hipLaunchKernelGGL((ste_vec_kernel<BF16, U, NT>), dim3((unsigned)((nvec + STE_THREADS * U - 1) / (STE_THREADS * U))), \
+                                  dim3(STE_THREADS), 0, 0, (const uint4*)b.g[i % NS], (const uint4*)b.x[i % NS], (uint4*)b.gx[i % NS], nvec, -2.0f, 2.0f); \
+           }, IT));
+    STE(1, false) STE(1, true) STE(2, true) STE(4, true)
+    // row-bounds variant: bounds were written by the sym launches above (weights: every row safe)
+    {
+        const int64_t chunks = (nv_row + 256 * 8 - 1) / (256 * 8);
+        const int cv = (int)((nv_row + chunks - 1) / chunks);
+        const int vpt = (cv + 255) / 256;
+        printf("ste_rows: chunks=%lld cv=%d vpt=%d\n", (long long)chunks, cv, vpt);
+#define STER(V, NT, LO, HI, LABEL)                                                                                                    \
+    if (vpt == V)                                                                                                                     \
+        report("ste_rows<VPT=" #V ",NT=" #NT "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                            \
+                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, NT>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI);                       \
+               }, IT));
+        STER(6, false, -2.0f, 2.0f, "all rows safe") STER(6, true, -2.0f, 2.0f, "all rows safe")
+        STER(6, false, -1e-3f, 1e-3f, "no row safe") STER(6, true, -1e-3f, 1e-3f, "no row safe")
+        STER(2, false, -2.0f, 2.0f, "all rows safe") STER(2, true, -2.0f, 2.0f, "all rows safe")
+        STER(2, false, -1e-3f, 1e-3f, "no row safe") STER(2, true, -1e-3f, 1e-3f, "no row safe")
+    }
+    return 0;
+}

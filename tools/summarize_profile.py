@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh run (gpurun_out/prof_<tag>) into the committed evidence under profiles/.
+
+    python tools/summarize_profile.py <tag>
+
+Writes
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --steps 50 --warmup 5`
+  profiles/<tag>_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes), with the
+                                    calibration on kernels of known byte count and the gfx950 correction
+  profiles/traffic.json             HBM bytes per launch for bench.py's `roofline.traffic`
+
+Correction (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
+streaming read -> doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Both are in KiB.
+The calibration rows (plain copy / read-only / write-only of a 90,177,536-byte buffer in tools/kbench) confirm both.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOWN = 4096 * 11008 * 2
+
+
+def counters(path):
+    d = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(path, "runc", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+def short(name):
+    return name.replace("void ", "").split("(")[0]
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+
+    # 1. kernel-trace stats
+    stats = glob.glob(os.path.join(src, "trace", "runc", "*_kernel_stats.csv"))[0]
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline  (MI355X, gfx950)"])
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"])[:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+    # per-dispatch durations of the STE kernel split by safe/unsafe cannot be told from the stats file; use the trace
+    trace = glob.glob(os.path.join(src, "trace", "runc", "*_kernel_trace.csv"))[0]
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "fq::" in r["Kernel_Name"]:
+            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+    # 2. PMC traffic
+    res = {"unit": "bytes per launch", "correction": "FETCH_SIZE KiB x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1",
+           "calibration": {}, "kernels": {}}
+    kbf, kbw = counters(os.path.join(src, "kb_fetch")), counters(os.path.join(src, "kb_write"))
+    for name in kbf:
+        if any(k in name for k in ("copy_kernel<4, false>", "copy_kernel<4, true>", "read_kernel<4>", "write_kernel<4>")):
+            res["calibration"][short(name)] = {
+                "known_read_bytes": 0 if "write_kernel" in name else KNOWN, "known_write_bytes": 0 if "read_kernel" in name else KNOWN,
+                "FETCH_SIZE_KiB_raw": statistics.median(kbf[name]), "WRITE_SIZE_KiB_raw": statistics.median(kbw.get(name, [0])),
+                "read_bytes_corrected": statistics.median(kbf[name]) * 2 * 1024, "write_bytes": statistics.median(kbw.get(name, [0])) * 1024}
+    bf, bw = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write"))
+    traffic = {}
+    for name in bf:
+        if "fq::" not in name:
+            continue
+        fv, wv = bf[name], bw.get(name, [])
+        entry = {"launches": len(fv)}
+        if "ste_rows" in name:  # bimodal: rows safe (g only) vs not (g and x)
+            cut = (min(fv) + max(fv)) / 2
+            for label, sel in (("rows_safe", [v for v in fv if v < cut]), ("rows_unsafe", [v for v in fv if v >= cut])):
+                if sel:
+                    rd = statistics.median(sel) * 2 * 1024
+                    wr = statistics.median(wv) * 1024 if wv else None
+                    entry[label] = {"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0), "launches": len(sel)}
+            if "rows_safe" in entry:
+                traffic["ste_bwd_w4"] = entry["rows_safe"]["total"]
+            if "rows_unsafe" in entry:
+                traffic["ste_bwd_a8"] = entry["rows_unsafe"]["total"]
+        else:
+            rd = statistics.median(fv) * 2 * 1024
+            wr = statistics.median(wv) * 1024 if wv else None
+            entry.update({"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0)})
+            if "row_reg_kernel" in name:
+                traffic["sym_fwd_w4"] = traffic["sym_fwd_a8"] = entry["total"]
+        d = dur.get(short(name))
+        if d:
+            entry["avg_duration_ns_unprofiled_trace"] = statistics.mean(d)
+        res["kernels"][short(name)] = entry
+    json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+    for k, v in dur.items():
+        print(f"{k[:90]:92s} n={len(v):4d} avg={statistics.mean(v)/1e3:8.2f} us  min={min(v)/1e3:8.2f}")
+
+
+if __name__ == "__main__":
+    main()

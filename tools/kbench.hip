@@ -82,6 +82,31 @@ __global__ __launch_bounds__(256) void copy_gs_kernel(const uint4* __restrict__ 
     }
 }
 
+// copy with an XCD-contiguous block remap: XCD k (= blockIdx % 8 under round-robin dispatch) streams the k-th eighth
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void copy_xcd_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nvec) {
+    const int64_t nb = gridDim.x, per = (nb + 7) / 8;
+    const int64_t b = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (b >= nb) return;
+    const int64_t v0 = b * (256 * UNR) + threadIdx.x;
+    uint4 r[UNR];
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        int64_t v = v0 + (int64_t)i * 256;
+        v = v < nvec ? v : nvec - 1;
+        if constexpr (NT) r[i] = ld_nt(&in[v]);
+        else r[i] = in[v];
+    }
+#pragma unroll
+    for (int i = 0; i < UNR; ++i) {
+        const int64_t v = v0 + (int64_t)i * 256;
+        if (v < nvec) {
+            if constexpr (NT) st_nt(&out[v], r[i]);
+            else out[v] = r[i];
+        }
+    }
+}
+
 template <int UNR>
 __global__ __launch_bounds__(256) void read_kernel(const uint4* __restrict__ in, uint32_t* __restrict__ out, int64_t nvec) {
     const int64_t v0 = (int64_t)blockIdx.x * (256 * UNR) + threadIdx.x;
@@ -190,6 +215,15 @@ int main(int argc, char** argv) {
                hipLaunchKernelGGL((copy_gs_kernel<U, NT>), dim3(G), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec); \
            }, IT));
     COPYGS(4, false, 2048) COPYGS(4, false, 4096) COPYGS(8, false, 2048) COPYGS(4, true, 2048) COPYGS(2, false, 4096)
+    report("copy_xcd<UNR=4,NT=true>", 2.0 * bytes, time_it([&](int i) {
+               const int64_t nb = (nvec + 1023) / 1024;
+               hipLaunchKernelGGL((copy_xcd_kernel<4, true>), dim3((unsigned)(((nb + 7) / 8) * 8)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec);
+           }, IT));
+    report("copy_xcd<UNR=1,NT=true>", 2.0 * bytes, time_it([&](int i) {
+               const int64_t nb = (nvec + 255) / 256;
+               hipLaunchKernelGGL((copy_xcd_kernel<1, true>), dim3((unsigned)(((nb + 7) / 8) * 8)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec);
+           }, IT));
+    COPY(1, true) COPY(2, true)
     uint32_t* sink;
     CK(hipMalloc(&sink, 64));
     report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
@@ -234,6 +268,17 @@ int main(int argc, char** argv) {
                }, IT));
         STER(6, false, -2.0f, 2.0f, "all rows safe") STER(6, true, -2.0f, 2.0f, "all rows safe")
         STER(6, false, -1e-3f, 1e-3f, "no row safe") STER(6, true, -1e-3f, 1e-3f, "no row safe")
+        // forced small chunks: cv = 256 / 512 vectors per block
+#define STERC(V, CV, LO, HI, LABEL)                                                                                                   \
+    {                                                                                                                                 \
+        const int64_t ch2 = (nv_row + CV - 1) / CV;                                                                                   \
+        report("ste_rows<VPT=" #V ",NT=1,cv=" #CV "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                        \
+                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, true>), dim3((unsigned)(rows * ch2)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, ch2, CV, b.bounds[i % NS], LO, HI);                          \
+               }, IT));                                                                                                               \
+    }
+        STERC(1, 256, -1e-3f, 1e-3f, "no row safe") STERC(2, 512, -1e-3f, 1e-3f, "no row safe") STERC(3, 768, -1e-3f, 1e-3f, "no row safe")
+        STERC(1, 256, -2.0f, 2.0f, "all rows safe") STERC(2, 512, -2.0f, 2.0f, "all rows safe") STERC(3, 768, -2.0f, 2.0f, "all rows safe")
         STER(2, false, -2.0f, 2.0f, "all rows safe") STER(2, true, -2.0f, 2.0f, "all rows safe")
         STER(2, false, -1e-3f, 1e-3f, "no row safe") STER(2, true, -1e-3f, 1e-3f, "no row safe")
     }

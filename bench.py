@@ -96,27 +96,45 @@ class Workload:
             a = a.bfloat16()
             gw = (torch.randn(rows, cols, generator=g, device=device) * 1e-3).bfloat16()
             ga = (torch.randn(rows, cols, generator=g, device=device) * 1e-3).bfloat16()
+            L = _lib.lib()
+            self.mask_bytes = L.fq_ste_mask_bytes(rows, cols, _lib.DTYPE_BF16)
             self.sets.append(dict(w=w, a=a, gw=gw, ga=ga, yw=torch.empty_like(w), ya=torch.empty_like(a),
                                   gxw=torch.empty_like(w), gxa=torch.empty_like(a),
-                                  bw=torch.empty(rows, 2, device=device), ba=torch.empty(rows, 2, device=device)))
-        L = _lib.lib()
+                                  bw=torch.empty(rows, 2, device=device), ba=torch.empty(rows, 2, device=device),
+                                  mw=torch.empty(self.mask_bytes, dtype=torch.uint8, device=device),
+                                  ma=torch.empty(self.mask_bytes, dtype=torch.uint8, device=device)))
         self.L, self._lib = L, _lib
         self.stream = torch.cuda.current_stream(device).cuda_stream
 
-    # raw C-ABI launches on preallocated buffers (what the autograd Functions do, minus the allocator)
+    # raw C-ABI launches on preallocated buffers (what the autograd Functions do, minus the allocator).
+    # Default data flow = the product's default ("mask" mode): fq_sym_fwd_train + fq_ste_bwd_mask.
     def fwd(self, s, leg):
-        x, y, b, bits = (s["w"], s["yw"], s["bw"], 4) if leg == "w" else (s["a"], s["ya"], s["ba"], 8)
+        x, y, b, m, bits = (s["w"], s["yw"], s["bw"], s["mw"], 4) if leg == "w" else (s["a"], s["ya"], s["ba"], s["ma"], 8)
+        rc = self.L.fq_sym_fwd_train(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16,
+                                     self._lib.SEM_CPU_EAGER, -2.0, 2.0, b.data_ptr(), m.data_ptr(), self.mask_bytes, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_sym_fwd_train")
+
+    def bwd(self, s, leg):
+        g, gx, b, m = (s["gw"], s["gxw"], s["bw"], s["mw"]) if leg == "w" else (s["ga"], s["gxa"], s["ba"], s["ma"])
+        rc = self.L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), self.rows, self.cols, -2.0, 2.0, b.data_ptr(), m.data_ptr(),
+                                    self.mask_bytes, self._lib.DTYPE_BF16, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_ste_bwd_mask")
+
+    # the reference's data flow (backward re-reads x), for comparison entries
+    def fwd_plain(self, s, leg):
+        x, y, bits = (s["w"], s["yw"], 4) if leg == "w" else (s["a"], s["ya"], 8)
         rc = self.L.fq_sym_fwd(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16,
-                               self._lib.SEM_CPU_EAGER, b.data_ptr(), None, 0, self.stream)
+                               self._lib.SEM_CPU_EAGER, None, None, 0, self.stream)
         if rc:
             self._lib.check(rc, "fq_sym_fwd")
 
-    def bwd(self, s, leg):
-        g, x, gx, b = (s["gw"], s["w"], s["gxw"], s["bw"]) if leg == "w" else (s["ga"], s["a"], s["gxa"], s["ba"])
-        rc = self.L.fq_ste_bwd_rows(g.data_ptr(), x.data_ptr(), gx.data_ptr(), self.rows, self.cols, -2.0, 2.0,
-                                    b.data_ptr(), self._lib.DTYPE_BF16, self.stream)
+    def bwd_xread(self, s, leg):
+        g, x, gx = (s["gw"], s["w"], s["gxw"]) if leg == "w" else (s["ga"], s["a"], s["gxa"])
+        rc = self.L.fq_ste_bwd(g.data_ptr(), x.data_ptr(), gx.data_ptr(), self.n, -2.0, 2.0, self._lib.DTYPE_BF16, self.stream)
         if rc:
-            self._lib.check(rc, "fq_ste_bwd_rows")
+            self._lib.check(rc, "fq_ste_bwd")
 
     def step(self, i):
         # forward on set i, backward on the set whose forward ran two steps ago: between the forward
@@ -272,7 +290,8 @@ def main():
         "config": {"workload": "SymQuantizer fwd + STE bwd, W4 on weight-style [4096,11008] + A8 on activation-style "
                                "[4096,11008], bf16, clip [-2,2] (LLaMA-7B W4-A8 down_proj shapes, configs[1])",
                    "elements_per_step": elems_step, "buffer_sets": wl.nsets, "parallelism": "replicas" if world > 1 else "1gpu",
-                   "semantics": "cpu_eager"},
+                   "semantics": "cpu_eager",
+                   "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x)"},
         "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
     }
 
@@ -288,6 +307,12 @@ def main():
         }
         kernels = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ks.items()]
         out["kernels"] = kernels
+        # the reference's data flow on the same kernels' siblings: forward without mask/bounds, backward re-reading x
+        alt = {
+            "sym_fwd_w4_plain": (lambda s: wl.fwd_plain(s, "w"), nb * FWD_BYTES_PER_ELEM),
+            "ste_bwd_a8_xread": (lambda s: wl.bwd_xread(s, "a"), nb * BWD_BYTES_PER_ELEM),
+        }
+        out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in alt.items()]
         dom = max(kernels, key=lambda e: e["us_per_launch"])
         out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         out["roofline"]["kernel"] = dom["kernel"]

@@ -53,6 +53,7 @@ extern "C" {
 #define FQ_ERR_WORKSPACE (-5)
 #define FQ_ERR_LAUNCH (-6)
 #define FQ_ERR_ARG (-7)
+#define FQ_ERR_UNSUPPORTED (-8) /* shape/alignment not served by this entry point: use the general one */
 
 int fq_version(void);               /* == FQ_ABI_VERSION */
 const char* fq_build_info(void);    /* e.g. "llmqat_fakequant abi 1, gfx950, hip 7.2" */
@@ -115,6 +116,30 @@ int fq_ste_bwd(const void* g, const void* x, void* gx, int64_t n, float lo, floa
  */
 int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi,
                     const float* row_bounds, int dtype, void* stream);
+
+/*
+ * Training-mode pair: the forward also records, for the backward, (a) the per-row bounds and (b) a
+ * 1-bit-per-element STE mask (only written for rows whose bounds do not already prove that nothing
+ * is clipped), so the backward never re-reads x:
+ *     forward  bf16: read x 2 + write y 2 (+ 1/8 mask)   backward: read g 2 (+ 1/8 mask) + write gx 2   B/element
+ * instead of 4 + 6.  Results are bit-identical to fq_*_fwd + fq_ste_bwd.  The autograd Functions need not
+ * keep `input` alive for the backward in this mode (the reference saves it, utils_quant.py:45).
+ *
+ * fq_ste_mask_bytes  size of the mask buffer for this shape; 0 if the shape is not served (rows that do
+ *                    not fit the register-resident kernels, or cols not a multiple of a 16-byte vector):
+ *                    use fq_*_fwd + fq_ste_bwd[_rows] then.  Contents need no initialisation.
+ * fq_*_fwd_train     lo/hi = the STE clip (clip_val[0], clip_val[1]); row_bounds_out and mask_out required.
+ *                    Returns FQ_ERR_UNSUPPORTED if x/y are not 16-byte aligned.
+ * fq_ste_bwd_mask    SymQuantizer.backward / AsymQuantizer.backward (utils_quant.py:77-87, :152-162) from
+ *                    (row_bounds, mask) of the matching forward; lo/hi must be the same values.
+ */
+size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype);
+int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
+                     float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
+                      float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,
+                    const void* mask, size_t mask_bytes, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,9 @@ EXPORTS = (
     "fq_version", "fq_build_info", "fq_last_error", "fq_rowwise_workspace_bytes",
     "fq_sym_fwd", "fq_asym_fwd", "fq_sym_fwd_debug", "fq_asym_fwd_debug",
     "fq_ste_bwd", "fq_ste_bwd_rows",
+    "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
 )
+ERR_UNSUPPORTED = -8
 
 _lock = threading.Lock()
 _lib = None
@@ -50,6 +52,14 @@ def _bind(L):
     L.fq_ste_bwd.restype = i32
     L.fq_ste_bwd_rows.argtypes = [vp, vp, vp, i64, i64, f32, f32, vp, i32, vp]
     L.fq_ste_bwd_rows.restype = i32
+    L.fq_ste_mask_bytes.argtypes = [i64, i64, i32]
+    L.fq_ste_mask_bytes.restype = sz
+    for name in ("fq_sym_fwd_train", "fq_asym_fwd_train"):
+        f = getattr(L, name)
+        f.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp]
+        f.restype = i32
+    L.fq_ste_bwd_mask.argtypes = [vp, vp, i64, i64, f32, f32, vp, vp, sz, i32, vp]
+    L.fq_ste_bwd_mask.restype = i32
     return L
 
 

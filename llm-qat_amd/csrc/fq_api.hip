@@ -76,9 +76,17 @@ Consts make_consts(int bits, int dt, int sem) {
     return c;
 }
 
+inline int esize_of(int dtype) { return dtype == FQ_DTYPE_F32 ? 4 : 2; }
+
+struct MaskArgs {
+    void* mask = nullptr;
+    size_t bytes = 0;
+    float lo = 0.f, hi = 0.f;
+};
+
 template <bool ASYM>
 int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, int64_t rows, int64_t cols, int bits, int dtype,
-            int sem, void* ws, size_t wsb, void* stream) {
+            int sem, void* ws, size_t wsb, void* stream, const MaskArgs* mk = nullptr) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (bits < (ASYM ? 1 : 2) || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [%d, 31]", bits, ASYM ? 1 : 2);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
@@ -87,7 +95,17 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, sem);
-    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym};
+    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f};
+    if (mk) {
+        if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
+        const int64_t mrw = mask_row_words(cols, esize_of(dtype));
+        if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
+        if (mk->bytes < (size_t)rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small: need %zu bytes", (size_t)rows * mrw * 8);
+        a.mask = (uint64_t*)mk->mask;
+        a.mask_row_words = mrw;
+        a.lo = host_rb(mk->lo, dtype);
+        a.hi = host_rb(mk->hi, dtype);
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool fast = !ASYM && bits <= 8;  // only honoured for bf16
     switch (dtype) {
@@ -135,6 +153,43 @@ FQ_API int fq_sym_fwd_debug(const void* x, void* y, int32_t* idx_out, float* sca
 FQ_API int fq_asym_fwd_debug(const void* x, void* y, int32_t* idx_out, float* scale_out, int64_t rows, int64_t cols, int bits,
                              int dtype, int sem, void* workspace, size_t workspace_bytes, void* stream) {
     return rowwise<true>(x, y, idx_out, scale_out, nullptr, rows, cols, bits, dtype, sem, workspace, workspace_bytes, stream);
+}
+
+FQ_API size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype) {
+    if (dtype < 0 || dtype > 2 || rows <= 0) return 0;
+    return (size_t)rows * (size_t)mask_row_words(cols, esize_of(dtype)) * 8;
+}
+
+FQ_API int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
+                            float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
+    MaskArgs mk;
+    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi;
+    return rowwise<false>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
+}
+FQ_API int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
+                             float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
+    MaskArgs mk;
+    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi;
+    return rowwise<true>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
+}
+
+FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,
+                           const void* mask, size_t mask_bytes, int dtype, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
+    if (rows == 0 || cols == 0) return ok();
+    if (!g || !gx || !row_bounds || !mask) return fail(FQ_ERR_NULL, "g / gx / row_bounds / mask must not be NULL");
+    const int64_t mrw = mask_row_words(cols, esize_of(dtype));
+    if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
+    if (mask_bytes < (size_t)rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
+    lo = host_rb(lo, dtype);
+    hi = host_rb(hi, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_ste_mask<F32>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
+        case FQ_DTYPE_F16: return launch_ste_mask<F16>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
+        default: return launch_ste_mask<BF16>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
+    }
 }
 
 FQ_API int fq_ste_bwd(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, int dtype, void* stream) {

@@ -233,10 +233,8 @@ __device__ __forceinline__ int32_t idx_i32(float q) {  // same coding as the ora
 // element chains on one dword.  `idx` (if non-null) receives EPD bin indices.
 // ------------------------------------------------------------------------------------
 // utils_quant.py:72   output = round(input * s).div(s + 1e-6)
-template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_dword(uint32_t w, const SymRow& r, int32_t* idx) {
+template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_chain(float (&f)[Ty<DT>::EPD], const SymRow& r, int32_t* idx) {
     using T = Ty<DT>;
-    float f[T::EPD];
-    T::unpack(w, f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * r.s;
     T::round_dt(f);
@@ -252,10 +250,15 @@ template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_dword(uint3
 }
 
 // utils_quant.py:144-147
-template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
+template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_dword(uint32_t w, const SymRow& r, int32_t* idx) {
+    float f[Ty<DT>::EPD];
+    Ty<DT>::unpack(w, f);
+    return sym_chain<DT, FAST>(f, r, idx);
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const AsymRow& r, const AsymConst& k, int32_t* idx) {
     using T = Ty<DT>;
-    float f[T::EPD];
-    T::unpack(w, f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] - r.mn;  // input - beta
     T::round_dt(f);
@@ -280,6 +283,12 @@ template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, con
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] + r.mn;  // + beta
     return T::pack(f);
+}
+
+template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
+    float f[Ty<DT>::EPD];
+    Ty<DT>::unpack(w, f);
+    return asym_chain<DT>(f, r, k, idx);
 }
 
 // min/max/NaN accumulation for Asym on one dword

@@ -10,11 +10,11 @@ namespace fq {
 // Launch shape of the register-resident kernel, from tools/kbench on MI355X: 2-3 vectors per
 // thread is the sweet spot (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
 // 4096 cols: 256 x 2 = 6.1 us, 128 x 4 = 6.3, 64 x 8 = 6.9, 512 x 1 = 7.7).
-template <int DT, bool ASYM, bool FAST, bool NT>
+template <int DT, bool ASYM, bool FAST, bool NT, bool DBG>
 static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #define R(TPR, V)                                                                                                   \
     case V:                                                                                                         \
-        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NT, NT>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),        \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NT, NT, DBG>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),   \
                   (TPR == 64 ? 256 : TPR), st, a);                                                                  \
         break;
     if (nvec <= 192) {
@@ -41,8 +41,13 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     bool two_pass = false, two_pass_vec = false;
     if (vec_ok && nvec <= REG_MAX_VEC) {
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
-        if (nt) launch_reg<DT, ASYM, FAST, true>(a, nvec, st);
-        else launch_reg<DT, ASYM, FAST, false>(a, nvec, st);
+        // the diagnostic outputs (bin indices, scales) live in their own instantiation so the product
+        // kernels carry none of that code; it runs the same arithmetic with the default cache policy
+        if (a.idx || a.scale) launch_reg<DT, ASYM, FAST, false, true>(a, nvec, st);
+        else if (nt) launch_reg<DT, ASYM, FAST, true, false>(a, nvec, st);
+        else launch_reg<DT, ASYM, FAST, false, false>(a, nvec, st);
+    } else if (a.mask) {
+        return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
     } else if (vec_ok) {
         two_pass = two_pass_vec = true;
     } else if (a.cols <= GENERIC_MAX_COLS) {
@@ -130,9 +135,36 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     return ok();
 }
 
+template <int DT>
+int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
+                    hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const int64_t mrw = mask_row_words(cols, T::ESIZE);
+    if (!mrw || !(aligned16(g) && aligned16(gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape/alignment not served");
+    const int64_t nvec_row = cols / EPV;
+    const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
+    int cv = (int)((nvec_row + chunks - 1) / chunks);
+    cv = (cv + 63) / 64 * 64;  // every wave covers exactly one 64-vector mask group per slot
+    const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
+    if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
+    const bool nt = rows * cols * T::ESIZE >= NT_MIN_BYTES;
+#define S(V)                                                                                                                            \
+    case V:                                                                                                                             \
+        if (nt) FQ_LAUNCH((ste_mask_kernel<DT, V, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi); \
+        else FQ_LAUNCH((ste_mask_kernel<DT, V, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);   \
+        break;
+    switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
+#undef S
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return ok();
+}
+
 #define FQ_INSTANTIATE(DT)                                                                                      \
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
-    template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t);
+    template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
+    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t);
 
 }  // namespace fq

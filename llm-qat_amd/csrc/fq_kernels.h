@@ -24,7 +24,48 @@ struct RowArgs {
     int64_t cols;
     SymConst sym;
     AsymConst asym;
+    // optional STE mask (register-resident kernels only): one bit per element, set where the
+    // backward must zero the gradient (x >= hi || x <= lo).  Written only for rows whose bounds
+    // do not already prove that nothing is clipped.  Layout: see ste_mask_store().
+    uint64_t* mask;
+    int64_t mask_row_words;
+    float lo, hi;
 };
+
+// STE bit mask layout (private to the forward/backward kernel pair, independent of launch shape):
+// the row's 16-byte vectors are taken in groups of 64 (one per lane of a wave); group G owns EPV
+// consecutive 64-bit words, word e holding, at bit l, the flag of element e of vector 64*G + l.
+// That is exactly what one __ballot per element position produces -- no bit transposes.
+// f = the vector's elements (already unpacked); SYMCLIP: lo == -hi, one |x| >= hi compare per element
+// (abs is a free source modifier; NaN compares false, i.e. passes the gradient, as in the reference).
+template <int N, bool SYMCLIP>
+__device__ __forceinline__ void ste_mask_store(const float (&f)[N], float lo, float hi, uint64_t* gw, int lane) {
+    uint64_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const bool m = SYMCLIP ? (__builtin_fabsf(f[e]) >= hi) : ((f[e] >= hi) || (f[e] <= lo));
+        const uint64_t b = __ballot(m);
+        if (lane == e) mine = b;
+    }
+    if (lane < N) gw[lane] = mine;
+}
+// apply group mask words (wave-uniform, in SGPRs) to this lane's gradient vector
+template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g, const uint64_t* mw, int lane) {
+    using T = Ty<DT>;
+    uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if constexpr (T::EPD == 1) {
+            if ((mw[d] >> lane) & 1ull) w[d] = 0u;
+        } else {
+            uint32_t keep = 0xFFFFFFFFu;
+            if ((mw[2 * d] >> lane) & 1ull) keep &= 0xFFFF0000u;
+            if ((mw[2 * d + 1] >> lane) & 1ull) keep &= 0x0000FFFFu;
+            w[d] &= keep;
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 // ------------------------------------------------------------------------------------
 // Register-resident row kernel.
@@ -33,7 +74,7 @@ struct RowArgs {
 //   Out-of-range slots re-load the row's last vector (idempotent for max/min), so no load
 //   sits behind a branch; only stores are predicated.
 // ------------------------------------------------------------------------------------
-template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true>
+template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
@@ -64,6 +105,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 
     SymRow sr;
     AsymRow ar;
+    float ub, lb;  // bounds of the row's values
     if constexpr (!ASYM) {
         uint32_t acc = 0;
 #pragma unroll
@@ -76,8 +118,10 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         const uint32_t mbits = block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]);
         const float m = as_f(mbits);
         sr = sym_row<DT>(m, a.sym);
+        ub = m;
+        lb = -m;
         if (t == 0) {
-            if (a.scale) a.scale[row] = sr.s;
+            if (DBG && a.scale) a.scale[row] = sr.s;
             if (a.bounds) {
                 a.bounds[2 * row] = m;
                 a.bounds[2 * row + 1] = -m;
@@ -103,8 +147,10 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         float mn = as_f(block_reduce<OpMinF, NW>(as_u(mm.mn), red[2]));
         if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
         ar = asym_row<DT>(mx, mn, a.asym);
+        ub = mx;
+        lb = mn;
         if (t == 0) {
-            if (a.scale) {
+            if (DBG && a.scale) {
                 a.scale[2 * row] = ar.al;
                 a.scale[2 * row + 1] = ar.mn;
             }
@@ -115,28 +161,47 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         }
     }
 
-    int32_t* idxr = a.idx ? a.idx + row * a.cols : nullptr;
+    // Elementwise pass.  Rows that can actually be clipped also emit the STE bit mask for the backward.
+    const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
+    const bool sym_clip = a.lo == -a.hi;
+    uint64_t* mrow = a.mask + row * a.mask_row_words;
+    int32_t* idxr = (DBG && a.idx) ? a.idx + row * a.cols : nullptr;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int v = t + i * TPR;
-        uint4 o;
+        const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        float f[EPV];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float fd[T::EPD];
+            T::unpack(w[d], fd);
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
+        }
+        if (want_mask && (v - (t & 63) < nvec)) {  // wave-uniform: this wave's 64-vector group exists
+            const int vc = v < nvec ? v : nvec - 1;  // r[i] holds vector vc (clamped load)
+            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(vc >> 6) * EPV;
+            if (sym_clip) ste_mask_store<EPV, true>(f, a.lo, a.hi, gw, t & 63);
+            else ste_mask_store<EPV, false>(f, a.lo, a.hi, gw, t & 63);
+        }
+        uint32_t o[4];
         int32_t ib[EPV];
-        if constexpr (!ASYM) {
-            o.x = sym_dword<DT, FAST>(r[i].x, sr, idxr ? ib + 0 * T::EPD : nullptr);
-            o.y = sym_dword<DT, FAST>(r[i].y, sr, idxr ? ib + 1 * T::EPD : nullptr);
-            o.z = sym_dword<DT, FAST>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
-            o.w = sym_dword<DT, FAST>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
-        } else {
-            o.x = asym_dword<DT>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
-            o.y = asym_dword<DT>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
-            o.z = asym_dword<DT>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
-            o.w = asym_dword<DT>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float fd[T::EPD];
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
+            int32_t* ip = (DBG && idxr) ? ib + d * T::EPD : nullptr;
+            if constexpr (!ASYM) o[d] = sym_chain<DT, FAST>(fd, sr, ip);
+            else o[d] = asym_chain<DT>(fd, ar, a.asym, ip);
         }
         if (v < nvec) {
-            st16<NTS>(&yr[v], o);
-            if (idxr) {
+            st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
+            if constexpr (DBG) {
+                if (idxr) {
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) idxr[(int64_t)v * EPV + e] = ib[e];
+                    for (int e = 0; e < EPV; ++e) idxr[(int64_t)v * EPV + e] = ib[e];
+                }
             }
         }
     }
@@ -505,6 +570,56 @@ __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __res
             o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
             o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
             o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
+            if (v < nvec) st16<NT>(&or_[v], o);
+        }
+    }
+}
+
+
+// STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
+// clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
+// every wave covers exactly one mask group per slot.
+template <int DT, int VPT, bool NT = true>
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nvec_row,
+                                                               int64_t chunks, int cv, const float* __restrict__ bounds,
+                                                               const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
+                                                               float hi) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const int64_t row = blockIdx.x / chunks;
+    const int64_t vs = (blockIdx.x % chunks) * cv;
+    const int64_t off = row * nvec_row + vs;
+    const uint4* gr = (const uint4*)g + off;
+    uint4* or_ = (uint4*)gx + off;
+    const int64_t rem = nvec_row - vs;
+    const int nvec = (int)(rem < cv ? rem : cv);
+    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+    const bool safe = (ub < hi) && (lb > lo);
+    const int t = threadIdx.x;
+    uint4 rg[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        int v = t + i * STE_THREADS;
+        v = v < nvec ? v : nvec - 1;
+        rg[i] = ld16<NT>(&gr[v]);
+    }
+    if (safe) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * STE_THREADS;
+            if (v < nvec) st16<NT>(&or_[v], rg[i]);
+        }
+    } else {
+        const uint64_t* mrow = mask + row * mask_row_words;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * STE_THREADS;
+            int vc = v < nvec ? v : nvec - 1;
+            const int64_t grp = __builtin_amdgcn_readfirstlane((int)((vs + vc) >> 6));
+            uint64_t mw[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) mw[e] = mrow[grp * EPV + e];  // wave-uniform address -> scalar loads
+            const uint4 o = ste_mask_apply<DT>(rg[i], mw, (int)((vs + v) & 63));
             if (v < nvec) st16<NT>(&or_[v], o);
         }
     }

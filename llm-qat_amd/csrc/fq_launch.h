@@ -30,6 +30,17 @@ constexpr int64_t WS_COLS_THRESHOLD = 32768; // rows longer than this may take t
 template <int DT> FQ_HIDDEN int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st);
 template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
 template <int DT>
+FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
+                              const uint64_t* mask, hipStream_t st);
+// words (uint64) of STE mask per row; 0 if the shape is not served by the mask path
+inline int64_t mask_row_words(int64_t cols, int esize) {
+    const int epv = 16 / esize;
+    if (cols <= 0 || cols % epv) return 0;
+    const int64_t nvec = cols / epv;
+    if (nvec > REG_MAX_VEC) return 0;
+    return (nvec + 63) / 64 * epv;
+}
+template <int DT>
 FQ_HIDDEN int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi,
                               const float* bounds, hipStream_t st);
 

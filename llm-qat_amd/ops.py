@@ -117,6 +117,45 @@ def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     return y, bounds, idx, scale
 
 
+def quantize_train(kind, x, num_bits, layerwise, lo, hi):
+    """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
+    not served by the STE-mask path (the caller then uses the general forward + x-based backward)."""
+    code = _prep(x, f"{kind}_quantize_train")
+    if x.numel() == 0 or not x.is_contiguous():
+        return None
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    L = _lib.lib()
+    mbytes = L.fq_ste_mask_bytes(rows, cols, code)
+    if not mbytes:
+        return None
+    y = torch.empty_like(x)
+    bounds = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    mask = torch.empty(mbytes, dtype=torch.uint8, device=x.device)
+    fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
+    with _DeviceOf(x):
+        rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, float(lo), float(hi),
+                bounds.data_ptr(), mask.data_ptr(), mbytes, _stream(x))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, f"{kind}_quantize_train")
+    return y, bounds, mask
+
+
+def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols):
+    """STE backward from the (row_bounds, mask) a quantize_train call recorded -- x is not needed."""
+    code = _prep(grad_output, "ste_backward_mask")
+    g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
+    gx = torch.empty_like(g)
+    if g.numel() == 0:
+        return gx
+    L = _lib.lib()
+    with _DeviceOf(g):
+        rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, float(lo), float(hi), row_bounds.data_ptr(),
+                               mask.data_ptr(), mask.numel(), code, _stream(g))
+    _lib.check(rc, "ste_backward_mask")
+    return gx
+
+
 def sym_quantize(x, num_bits, layerwise=False, want_bounds=False):
     """SymQuantizer.forward (utils_quant.py:37-74).  -> y, or (y, row_bounds) if want_bounds."""
     y, bounds, _, _ = _rowwise("sym", x, num_bits, layerwise, want_bounds, False)

@@ -18,9 +18,27 @@ import torch.nn as nn
 
 from . import ops
 
-# Record per-row value bounds in forward so backward can skip re-reading x for rows that
-# cannot be clipped (weights practically always): 4 instead of 6 bytes/element of HBM traffic.
-_ROW_BOUNDS = os.environ.get("LLMQAT_AMD_ROW_BOUNDS", "1") != "0"
+# How the backward learns which gradients to zero (results are identical in all three modes):
+#   "mask"   (default) the forward records per-row value bounds + a 1-bit/element STE mask for rows
+#            that can be clipped; the backward reads g (+ mask) only -- x is neither re-read nor
+#            kept alive by the autograd node.  bf16: 4 + 4.1 instead of 4 + 6 bytes/element.
+#   "bounds" the forward records only the per-row bounds; the backward re-reads x for rows that
+#            can be clipped (weights practically never can).
+#   "plain"  nothing recorded; the backward re-reads x everywhere (the reference's data flow).
+_BACKWARD_MODE = os.environ.get("LLMQAT_AMD_BACKWARD", "mask")
+if os.environ.get("LLMQAT_AMD_ROW_BOUNDS", "1") == "0":
+    _BACKWARD_MODE = "plain"
+
+
+def set_backward_mode(mode):
+    global _BACKWARD_MODE
+    if mode not in ("mask", "bounds", "plain"):
+        raise ValueError(mode)
+    _BACKWARD_MODE = mode
+
+
+def get_backward_mode():
+    return _BACKWARD_MODE
 
 
 def _clip_pair(clip_val):
@@ -33,20 +51,35 @@ class _FakeQuantFunction(torch.autograd.Function):
 
     @staticmethod
     def _fwd(kind, ctx, input, clip_val, num_bits, layerwise):
-        ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
-        use_bounds = _ROW_BOUNDS and ctx.needs_input_grad[0]
-        fn = ops.sym_quantize if kind == "sym" else ops.asym_quantize
-        if use_bounds:
-            out, bounds = fn(input, num_bits, layerwise, want_bounds=True)
-            ctx.row_bounds = bounds
+        mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
+        ctx.fq_mode = "plain"
+        ctx.row_bounds = ctx.ste_mask = None
+        if mode != "plain":
             ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
+        if mode == "mask":
+            lo, hi = _clip_pair(clip_val)
+            res = ops.quantize_train(kind, input, num_bits, layerwise, lo, hi)
+            if res is not None:
+                out, ctx.row_bounds, ctx.ste_mask = res
+                ctx.fq_mode, ctx.clip = "mask", (lo, hi)
+                ctx.in_shape = input.shape
+                return out  # the input itself is not needed again
+            mode = "bounds"
+        ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
+        fn = ops.sym_quantize if kind == "sym" else ops.asym_quantize
+        if mode == "bounds":
+            out, ctx.row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
+            ctx.fq_mode = "bounds"
         else:
             out = fn(input, num_bits, layerwise)
-            ctx.row_bounds = None
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
+        if ctx.fq_mode == "mask":
+            lo, hi = ctx.clip
+            rows, cols = ctx.rows_cols
+            return ops.ste_backward_mask(grad_output, lo, hi, ctx.row_bounds, ctx.ste_mask, rows, cols), None, None, None
         input, clip_val = ctx.saved_tensors  # reference :83 / :158
         lo, hi = _clip_pair(clip_val)
         bounds = ctx.row_bounds

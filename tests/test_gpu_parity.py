@@ -76,10 +76,22 @@ def test_ste_backward_golden(ops):
         assert (a == b).all(), c["name"]
 
 
-def test_autograd_functions_golden(ops):
-    """SymQuantizer / AsymQuantizer .apply + .backward through autograd, CPU clip tensor as in the reference."""
+@pytest.mark.parametrize("mode", ["mask", "bounds", "plain"])
+def test_autograd_functions_golden(ops, mode):
+    """SymQuantizer / AsymQuantizer .apply + .backward through autograd, CPU clip tensor as in the reference;
+    all three backward data flows give the reference's gradient bit for bit."""
+    import llm_qat_amd
     from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
     G = golden("ste_bwd.npz")
+    prev = llm_qat_amd.get_backward_mode()
+    llm_qat_amd.set_backward_mode(mode)
+    try:
+        _autograd_golden(G, SymQuantizer, AsymQuantizer)
+    finally:
+        llm_qat_amd.set_backward_mode(prev)
+
+
+def _autograd_golden(G, SymQuantizer, AsymQuantizer):
     for c in G.cases:
         dt = c["dtype"]
         quant = SymQuantizer if c["quant"] == "SymQuantizer" else AsymQuantizer
@@ -211,6 +223,49 @@ def test_ste_row_bounds_path_equals_plain(ops, dtype):
         assert (b[ok, 0] == xf[ok].max(axis=1)).all() and (b[ok, 1] == xf[ok].min(axis=1)).all()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_train_mode_mask_path_vs_oracle(ops, kind, dtype):
+    """fq_*_fwd_train + fq_ste_bwd_mask: forward values and the gradient (computed WITHOUT x) are bit-equal to
+    the oracle's; covers partial 64-vector groups, multi-chunk rows, safe + unsafe + NaN rows, custom clips."""
+    rng = np.random.default_rng(77)
+    shapes = [(5, 8), (3, 264), (7, 512), (4, 520), (6, 4096), (3, 11008), (2, 13824), (2, 32768), (9, 64), (2, 65536)]
+    for shape in shapes:
+        x_np, x = make_input(rng, shape, dtype, "mixed")
+        if shape[0] > 2:
+            x[1, shape[1] // 2] = float("nan")
+            x[2, 0] = 2.0
+            x[2, shape[1] - 1] = -2.0
+            x_np = np_from(x)
+        g_np, g = make_input(rng, shape, dtype, "weight")
+        for lo, hi, bits in ((-2.0, 2.0, 8), (-0.5, 0.75, 4), (-0.3009, 0.3009, 4)):
+            res = ops.quantize_train(kind, x, bits, False, lo, hi)
+            if res is None:
+                assert shape[1] * (4 if dtype == "fp32" else 2) > 8192 * 16, f"{shape} should be served"
+                continue
+            y, bounds, mask = res
+            if kind == "sym":
+                yo, _, _ = O.sym_fwd(x_np, shape[0], shape[1], bits, dtype)
+            else:
+                yo, _, _, _ = O.asym_fwd(x_np, shape[0], shape[1], bits, dtype)
+            assert bits_equal(np_from(y), yo, dtype), f"{kind} {dtype} {shape} fwd"
+            gx = ops.ste_backward_mask(g, lo, hi, bounds, mask, shape[0], shape[1])
+            want = O.ste_bwd(g_np, x_np, lo, hi, dtype)
+            assert bits_equal(np_from(gx), want, dtype), f"{kind} {dtype} {shape} clip=({lo},{hi}): {mismatch_report(np_from(gx), want, dtype)}"
+
+
+def test_mask_mode_does_not_keep_input_alive(ops):
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import SymQuantizer
+    assert llm_qat_amd.get_backward_mode() == "mask"
+    x = torch.randn(64, 4096, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    y = SymQuantizer.apply(x, torch.tensor([-2.0, 2.0]), 8, False)
+    assert y.grad_fn is not None and len(y.grad_fn.saved_tensors) == 0    # nothing saved: bounds + mask live on the ctx
+    y.sum().backward()
+    ref = torch.where((x >= 2) | (x <= -2), torch.zeros_like(x), torch.ones_like(x))
+    assert torch.equal(x.grad, ref)
+
+
 def test_non_contiguous_and_misaligned_inputs(ops):
     rng = np.random.default_rng(8)
     base = torch.from_numpy(rng.standard_normal((64, 48)).astype(np.float32)).cuda().bfloat16()
@@ -288,6 +343,9 @@ def test_full_size_properties(ops, shape, bits, style):
     _, bounds = ops.sym_quantize(x, bits, False, want_bounds=True)
     gx2 = ops.ste_backward(gg, x, -2.0, 2.0, row_bounds=bounds, rows_cols_hint=shape)
     assert torch.equal(gx2, ref)
+    y3, b3, m3 = ops.quantize_train("sym", x, bits, False, -2.0, 2.0)
+    assert torch.equal(y3, y)
+    assert torch.equal(ops.ste_backward_mask(gg, -2.0, 2.0, b3, m3, shape[0], shape[1]), ref)
 
 
 # ------------------------------------------------------------------------------------------

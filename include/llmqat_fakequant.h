@@ -141,6 +141,20 @@ int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bi
 int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,
                     const void* mask, size_t mask_bytes, int dtype, void* stream);
 
+/*
+ * QuantizeLinear's 1- and 2-bit weight branches -- models/utils_quant.py:202-242, elementwise part:
+ *   w_bits==1 : q = sc * sign(w / sc)
+ *   w_bits==2 : q = sc * (round(clamp(w / sc, -0.99, 0.99) * 2 - 0.5) + 0.5) / 2
+ *   out = (q - w) + w          (the forward value of `q.detach() - w.detach() + w`, :240-242)
+ * `scale` = the mean-|w| scaling factor the caller reduced (mean|w| for 1 bit, 2*mean|w| for 2 bits; :205-209,
+ * :219-224), in the tensor dtype: [rows] values if scale_per_row, else one value (weight_layerwise).  It is an input
+ * because a floating-point SUM depends on the reduction order: keeping ATen's reduction keeps the result
+ * bit-identical to the reference's; this call fuses the ~10 elementwise ATen kernels that follow it into one.
+ * The gradient of these branches is the identity (no kernel).
+ */
+int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
+               int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,6 +192,24 @@ FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, 
     }
 }
 
+FQ_API int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
+                      int dtype, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (w_bits != 1 && w_bits != 2) return fail(FQ_ERR_BITS, "w_bits=%d: this entry point serves 1 and 2", w_bits);
+    if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
+    if (rows == 0 || cols == 0) return ok();
+    if (!w || !scale || !out) return fail(FQ_ERR_NULL, "w / scale / out must not be NULL");
+    // clip_val = 1 - 1e-2 (utils_quant.py:217): a Python double; the clamp compares in fp32 on the device and in the
+    // tensor dtype on the CPU -- both give the same results (DESIGN.md "Numerics"), fp32 is used here
+    const float cv = (float)(1.0 - 1e-2);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_w12<F32>(w, scale, out, rows, cols, w_bits, scale_per_row, cv, st);
+        case FQ_DTYPE_F16: return launch_w12<F16>(w, scale, out, rows, cols, w_bits, scale_per_row, cv, st);
+        default: return launch_w12<BF16>(w, scale, out, rows, cols, w_bits, scale_per_row, cv, st);
+    }
+}
+
 FQ_API int fq_ste_bwd(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, int dtype, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (n < 0) return fail(FQ_ERR_SHAPE, "negative n");

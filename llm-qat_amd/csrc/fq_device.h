@@ -291,6 +291,29 @@ template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, con
     return asym_chain<DT>(f, r, k, idx);
 }
 
+// QuantizeLinear's 1-/2-bit weight branches (utils_quant.py:203-242), forward value INCLUDING the
+// detach trick  weight = q.detach() - w.detach() + w  (two more roundings; gradient is the identity).
+//   1 bit : q = sc * sign(w / sc)                                            sign(NaN) = sign(0) = 0, as torch.sign
+//   2 bit : q = sc * (round(clamp(w / sc, -cv, cv) * 2 - 0.5) + 0.5) / 2     cv = 0.99 (clamp propagates NaN)
+template <int DT, int WBITS> __device__ __forceinline__ float w12_elem(float w, float sc, float cv) {
+    using T = Ty<DT>;
+    const float t = T::rb(w / sc);
+    float q;
+    if constexpr (WBITS == 1) {
+        const float sg = (t > 0.f) ? 1.f : (t < 0.f) ? -1.f : 0.f;
+        q = T::rb(sc * sg);
+    } else {
+        const float c = (t != t) ? t : __builtin_fminf(__builtin_fmaxf(t, -cv), cv);
+        float u = T::rb(T::rb(c) * 2.0f);
+        u = T::rb(u - 0.5f);
+        u = __builtin_rintf(u);
+        u = T::rb(u + 0.5f);
+        u = T::rb(sc * u);
+        q = T::rb(u / 2.0f);
+    }
+    return T::rb(q - w) + w;  // rounded once more by the store
+}
+
 // min/max/NaN accumulation for Asym on one dword
 struct MinMax {
     float mx, mn;

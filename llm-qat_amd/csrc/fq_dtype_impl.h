@@ -161,10 +161,32 @@ int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
     return ok();
 }
 
+template <int DT>
+int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, float cv,
+               hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const bool vec = aligned16(w) && aligned16(out) && cols % EPV == 0;
+    int64_t grid = vec ? (rows * (cols / EPV) + 255) / 256 : (rows * cols + 255) / 256;
+    if (!vec && grid > 16384) grid = 16384;
+    if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "tensor too large");
+    if (w_bits == 1) {
+        if (vec) FQ_LAUNCH((w12_kernel<DT, 1, true>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
+        else FQ_LAUNCH((w12_kernel<DT, 1, false>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
+    } else {
+        if (vec) FQ_LAUNCH((w12_kernel<DT, 2, true>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
+        else FQ_LAUNCH((w12_kernel<DT, 2, false>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return ok();
+}
+
 #define FQ_INSTANTIATE(DT)                                                                                      \
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
-    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t);
+    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t); \
+    template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 
 }  // namespace fq

@@ -576,6 +576,40 @@ __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __res
 }
 
 
+// 1-/2-bit weight branch, elementwise part (the per-row mean|w| scale is an input: it comes from the
+// caller's own reduction so that the result stays bit-identical to the reference's).
+// VEC: 16-byte vectors, one per thread; otherwise one element per thread (grid-stride).
+template <int DT, int WBITS, bool VEC>
+__global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, const void* __restrict__ scale, void* __restrict__ out,
+                                                  int64_t rows, int64_t cols, int scale_per_row, float cv) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    if constexpr (VEC) {
+        const int64_t nvec_row = cols / EPV, nvec = rows * nvec_row;
+        const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (v >= nvec) return;
+        const float sc = T::load1(scale, scale_per_row ? v / nvec_row : 0);
+        const uint4 r = ((const uint4*)w)[v];
+        const uint32_t in[4] = {r.x, r.y, r.z, r.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float f[T::EPD];
+            T::unpack(in[d], f);
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv);
+            o[d] = T::pack(f);
+        }
+        ((uint4*)out)[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        const int64_t n = rows * cols, stride = (int64_t)gridDim.x * 256;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float sc = T::load1(scale, scale_per_row ? i / cols : 0);
+            T::store1(out, i, w12_elem<DT, WBITS>(T::load1(w, i), sc, cv));
+        }
+    }
+}
+
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
 // clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
 // every wave covers exactly one mask group per slot.

@@ -156,6 +156,26 @@ def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols):
     return gx
 
 
+def low_bit_weight(w, scale, w_bits):
+    """Elementwise part of QuantizeLinear's 1-/2-bit weight branch (utils_quant.py:203-242), forward value of
+    `q.detach() - w.detach() + w`.  `scale`: [rows, 1] / [rows] per-row or 0-dim layerwise, same dtype as w."""
+    code = _prep(w, "low_bit_weight")
+    if w.dim() != 2:
+        raise ValueError("low_bit_weight expects a 2-D weight")
+    wc = w if w.is_contiguous() else w.contiguous()
+    sc = scale.to(w.dtype).contiguous()
+    per_row = 1 if sc.numel() == w.shape[0] and sc.numel() != 1 else 0
+    if not per_row and sc.numel() != 1:
+        raise ValueError(f"scale has {sc.numel()} elements for a weight with {w.shape[0]} rows")
+    out = torch.empty_like(wc)
+    if wc.numel():
+        with _DeviceOf(w):
+            rc = _lib.lib().fq_w12_fwd(wc.data_ptr(), sc.data_ptr(), out.data_ptr(), wc.shape[0], wc.shape[1], int(w_bits),
+                                       per_row, code, _stream(w))
+        _lib.check(rc, "low_bit_weight")
+    return out
+
+
 def sym_quantize(x, num_bits, layerwise=False, want_bounds=False):
     """SymQuantizer.forward (utils_quant.py:37-74).  -> y, or (y, row_bounds) if want_bounds."""
     y, bounds, _, _ = _rowwise("sym", x, num_bits, layerwise, want_bounds, False)

@@ -12,6 +12,8 @@ so `models/modeling_llama_quant.py` (which imports them by name, :51) and everyt
 single-pass HIP kernels for gfx950 (see INTEGRATION.md for the one-line switch).
 """
 import os
+import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -106,7 +108,97 @@ class AsymQuantizer(_FakeQuantFunction):
         return _FakeQuantFunction._fwd("asym", ctx, input, clip_val, num_bits, layerwise)
 
 
+class _LowBitWeight(torch.autograd.Function):
+    """forward value of `quan_weights_no_grad.detach() - real_weights.detach() + real_weights` (:240-242);
+    its gradient w.r.t. real_weights is the identity."""
+
+    @staticmethod
+    def forward(ctx, w, scale, w_bits):
+        return ops.low_bit_weight(w, scale, w_bits)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None, None
+
+
 _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every call (:198, :245)
+
+# ---------------------------------------------------------------------------------------------
+# Call-site redundancy the reference has (SURVEY §3.4 / §8f), removed without changing any result:
+#
+# 1. q_proj / k_proj / v_proj (modeling_llama_quant.py:313,317,318) and gate_proj / up_proj (:235)
+#    fake-quantize the SAME activation tensor with the same bits.  `_shared_activation` remembers the
+#    last (input -> output) pair per thread and hands the same output (and autograd node) to the
+#    sibling projections.  Gradients are unchanged bit for bit: the STE mask is applied once to the
+#    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum.
+#    A hit requires the very same tensor object at the same version; the remembered output is released as
+#    soon as that input tensor dies (weak reference + callback), so nothing outlives the caller's own use.
+# 2. Under activation checkpointing every weight is fake-quantized twice per step (first forward, then
+#    the recompute -- reentrant or not) although it has not changed.  With the weight cache on (opt-in:
+#    it keeps one quantized copy per layer alive from the first use until the second), the second use
+#    within a step reuses the first result.  The key holds the parameter's identity, version counter and
+#    storage address, so an optimizer step / load_state_dict / .data swap can never be served stale.
+# ---------------------------------------------------------------------------------------------
+_SHARE_ACT = os.environ.get("LLMQAT_AMD_SHARE_ACT", "1") != "0"
+_WEIGHT_CACHE = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") == "1"
+_tls = threading.local()
+
+
+def share_activation_quant(flag=True):
+    global _SHARE_ACT
+    _SHARE_ACT = bool(flag)
+
+
+def enable_weight_quant_cache(flag=True):
+    global _WEIGHT_CACHE
+    _WEIGHT_CACHE = bool(flag)
+
+
+def _shared_activation(quantizer, x, num_bits, layerwise):
+    if not _SHARE_ACT:
+        return quantizer.apply(x, _CLIP, num_bits, layerwise)
+    cache = getattr(_tls, "act", None)
+    if cache is None:
+        cache = _tls.act = {}
+    key = (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics())
+    ent = cache.get(key)
+    if ent is not None:
+        rin, ver_in, y, ver_out = ent
+        if rin() is x and ver_in == x._version and ver_out == y._version:
+            return y
+    y = quantizer.apply(x, _CLIP, num_bits, layerwise)
+
+    def _drop(ref, cache=cache, key=key):  # the input died: nobody can ask for this result again
+        ent = cache.get(key)
+        if ent is not None and ent[0] is ref:
+            del cache[key]
+
+    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version)
+    return y
+
+
+class _ReuseQuantizedWeight(torch.autograd.Function):
+    """Autograd node over an already computed (value, row bounds, STE mask) triple of a weight:
+    forward launches nothing, backward is the ordinary STE backward."""
+
+    @staticmethod
+    def forward(ctx, weight, cached, clip_val):
+        y, bounds, mask, rows_cols = cached
+        ctx.row_bounds, ctx.ste_mask, ctx.rows_cols = bounds, mask, rows_cols
+        ctx.clip = _clip_pair(clip_val)
+        if mask is None:
+            ctx.save_for_backward(weight)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lo, hi = ctx.clip
+        if ctx.ste_mask is not None:
+            rows, cols = ctx.rows_cols
+            return ops.ste_backward_mask(grad_output, lo, hi, ctx.row_bounds, ctx.ste_mask, rows, cols), None, None
+        (weight,) = ctx.saved_tensors
+        bounds = ctx.row_bounds if grad_output.is_contiguous() and weight.is_contiguous() else None
+        return ops.ste_backward(grad_output, weight, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols), None, None
 
 
 class QuantizeLinear(nn.Linear):
@@ -121,30 +213,49 @@ class QuantizeLinear(nn.Linear):
             self.act_quantizer = SymQuantizer if symmetric else AsymQuantizer
 
     def _low_bit_weight(self, w):
-        """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding,
-        identity gradient through the detach trick.  Eager torch for now."""
-        dims = None if self.weight_layerwise else 1
-        absmean = w.abs().mean() if dims is None else w.abs().mean(dim=1, keepdim=True)
-        if self.w_bits == 1:
-            sc = absmean.detach()
-            q = sc * torch.sign(w / sc)
+        """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding, identity
+        gradient (the reference's detach trick).  The mean stays ATen's reduction (a sum is order dependent;
+        this keeps the scale bit-identical to the reference's); the ~10 elementwise kernels after it are one
+        HIP kernel."""
+        with torch.no_grad():
+            absmean = w.abs().mean() if self.weight_layerwise else w.abs().mean(dim=1, keepdim=True)
+            sc = absmean if self.w_bits == 1 else 2 * absmean
+        return _LowBitWeight.apply(w, sc, self.w_bits)
+
+    def _quantized_weight(self):
+        w = self.weight
+        if not _WEIGHT_CACHE or not w.is_cuda:
+            return SymQuantizer.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
+        key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics())
+        ent = getattr(self, "_fq_wcache", None)
+        if ent is not None and ent[0] == key:
+            cached = ent[1]
+            self._fq_wcache = None  # second use within the step (the checkpoint recompute): done with it
         else:
-            levels = 2 ** (self.w_bits - 1)
-            bound = 1 - 1e-2
-            sc = (2 * absmean).detach()
-            q = sc * (torch.round(torch.clamp(w / sc, -bound, bound) * levels - 0.5) + 0.5) / levels
-        return q.detach() - w.detach() + w
+            rc = ops.rows_cols(tuple(w.shape), self.weight_layerwise)
+            res = ops.quantize_train("sym", w, self.w_bits, self.weight_layerwise, -2.0, 2.0) if _BACKWARD_MODE == "mask" else None
+            if res is not None:
+                y, bounds, mask = res
+            elif _BACKWARD_MODE == "plain":
+                y, bounds, mask = ops.sym_quantize(w, self.w_bits, self.weight_layerwise), None, None
+            else:
+                (y, bounds), mask = ops.sym_quantize(w, self.w_bits, self.weight_layerwise, want_bounds=True), None
+            cached = (y, bounds, mask, rc)
+            self._fq_wcache = (key, cached)
+        if torch.is_grad_enabled() and w.requires_grad:
+            return _ReuseQuantizedWeight.apply(w, cached, _CLIP)  # launches nothing; backward = the ordinary STE
+        return cached[0]
 
     def forward(self, input_):
         assert len(self.weight.size()) == 2
         if self.w_bits >= 32:
             weight = self.weight
         elif self.w_bits >= 3:
-            weight = SymQuantizer.apply(self.weight, _CLIP, self.w_bits, self.weight_layerwise)
+            weight = self._quantized_weight()
         else:
             weight = self._low_bit_weight(self.weight)
         if 2 < self.a_bits < 32:
-            input_ = self.act_quantizer.apply(input_, _CLIP, self.a_bits, self.act_layerwise)
+            input_ = _shared_activation(self.act_quantizer, input_, self.a_bits, self.act_layerwise)
         out = nn.functional.linear(input_, weight)
         if self.bias is not None:
             out += self.bias.view(1, -1).expand_as(out)

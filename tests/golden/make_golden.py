@@ -313,6 +313,51 @@ def build_linear():
     return arrays, manifest
 
 
+# --------------------------------------------------------------------------------------
+# 1-/2-bit weight branches of QuantizeLinear (utils_quant.py:202-242): the tensor handed to F.linear
+# --------------------------------------------------------------------------------------
+def build_w12():
+    import torch.nn.functional as F
+    arrays, manifest = {}, []
+    gen = torch.Generator().manual_seed(31337)
+    captured = {}
+    real_linear = F.linear
+
+    def spy(inp, weight, bias=None):
+        captured["w"] = weight.detach().clone()
+        return real_linear(inp, weight, bias)
+
+    for dname, dt in DT.items():
+        for w_bits in (1, 2):
+            for layerwise in (False, True):
+                for shape in [(6, 40), (3, 33), (5, 256)]:
+                    w = torch.randn(shape, generator=gen) * 0.05
+                    if shape == (6, 40):
+                        w[1] = 0.0                      # all-zero row: scale 0 -> 0/0
+                        w[2, :5] = torch.tensor([1e-3, -1e-3, 0.0, 5.0, -5.0])
+                        w[3, 0] = float("nan")
+                        w[4] *= 1e-6
+                    lin = QuantizeLinear(shape[1], shape[0], w_bits=w_bits, a_bits=32, weight_layerwise=layerwise)
+                    lin.weight.data = w.to(dt)
+                    F.linear = torch.nn.functional.linear = spy
+                    try:
+                        lin(torch.zeros(1, shape[1], dtype=dt))
+                    finally:
+                        F.linear = torch.nn.functional.linear = real_linear
+                    wq = captured["w"]
+                    real = lin.weight.data
+                    if layerwise:
+                        sc = torch.mean(abs(real)) if w_bits == 1 else 2 * torch.mean(abs(real))
+                    else:
+                        sc = torch.mean(abs(real), dim=1, keepdim=True) if w_bits == 1 else 2 * torch.mean(abs(real), dim=1, keepdim=True)
+                    name = f"w12_{dname}_b{w_bits}_{'lw' if layerwise else 'row'}_{shape[0]}x{shape[1]}"
+                    arrays[f"{name}/w"] = to_np(real)
+                    arrays[f"{name}/scale"] = to_np(sc.reshape(-1).contiguous())
+                    arrays[f"{name}/wq"] = to_np(wq)
+                    manifest.append(dict(name=name, dtype=dname, w_bits=w_bits, layerwise=layerwise, shape=list(shape)))
+    return arrays, manifest
+
+
 def main():
     torch.set_num_threads(1)
     meta = dict(torch=torch.__version__, numpy=np.__version__, reference="JingyangXiang/LLM-QAT @ 2024_08_07",
@@ -322,6 +367,7 @@ def main():
         "asym_fwd.npz": build_fwd("asym"),
         "ste_bwd.npz": build_bwd(),
         "quantize_linear.npz": build_linear(),
+        "w12.npz": build_w12(),
     }.items():
         arrays["manifest"] = np.frombuffer(json.dumps(dict(meta=meta, cases=manifest)).encode(), dtype=np.uint8)
         path = os.path.join(HERE, fname)

@@ -1,0 +1,241 @@
+"""GPU tier: the widened rows of SURVEY §8f and the ABI's concurrency / capture claims.
+  * 1-/2-bit weight branches (utils_quant.py:202-242) vs golden + oracle + live ATen
+  * shared activation quant for sibling projections; weight-quant reuse across checkpoint recompute
+  * hipGraph capture of the C-ABI calls; use from several streams and from the autograd thread
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from conftest import bits_equal, golden, mismatch_report, to_f32
+from oracle import oracle as O
+from test_gpu_parity import TD, dev_from, np_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import llm_qat_amd
+    from llm_qat_amd import _lib
+    _lib.lib()
+    return llm_qat_amd
+
+
+# ------------------------------------------------------------------------------------------ W1 / W2
+def test_low_bit_weight_golden(pkg):
+    G = golden("w12.npz")
+    for c in G.cases:
+        dt = c["dtype"]
+        w = dev_from(G.arr(c, "w"), dt)
+        sc = dev_from(G.arr(c, "scale"), dt)
+        q = pkg.ops.low_bit_weight(w, sc if not c["layerwise"] else sc.reshape(()), c["w_bits"])
+        assert bits_equal(np_from(q), G.arr(c, "wq"), dt), f"{c['name']}: {mismatch_report(np_from(q), G.arr(c, 'wq'), dt)}"
+
+
+def eager_low_bit(w, w_bits, layerwise):
+    """the reference's op chain for the branch (utils_quant.py:203-242), run by ATen on the device"""
+    if w_bits == 1:
+        sc = torch.mean(abs(w)).detach() if layerwise else torch.mean(abs(w), dim=1, keepdim=True).detach()
+        q = sc * torch.sign(w / sc)
+    else:
+        nb, cv = 2 ** (w_bits - 1), 1 - 1e-2
+        sc = 2 * torch.mean(abs(w)).detach() if layerwise else 2 * torch.mean(abs(w), dim=1, keepdim=True).detach()
+        q = sc * (torch.round(torch.clamp(w / sc, -cv, cv) * nb - 0.5) + 0.5) / nb
+    return q.detach() - w.detach() + w
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+def test_low_bit_module_vs_live_aten(pkg, dtype):
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for (out_f, in_f) in [(64, 256), (33, 100), (128, 11008), (7, 4097)]:
+        for w_bits in (1, 2):
+            for lw in (False, True):
+                lin = QuantizeLinear(in_f, out_f, w_bits=w_bits, a_bits=32, weight_layerwise=lw).cuda().to(TD[dtype])
+                with torch.no_grad():
+                    lin.weight.copy_(torch.randn(out_f, in_f, generator=g, device="cuda") * 0.05)
+                x = torch.randn(3, in_f, generator=g, device="cuda").to(TD[dtype])
+                out = lin(x)
+                wref = lin.weight.detach().clone().requires_grad_(True)
+                ref = F.linear(x, eager_low_bit(wref, w_bits, lw))
+                assert torch.equal(out, ref), (dtype, out_f, in_f, w_bits, lw)
+                go = torch.randn_like(out)
+                out.backward(go)
+                ref.backward(go)
+                assert torch.equal(lin.weight.grad, wref.grad)       # identity STE for these branches
+
+
+# ------------------------------------------------------------------------------------------ sharing
+class Counter:
+    def __init__(self, mod, names):
+        self.mod, self.names, self.n = mod, names, 0
+
+    def __enter__(self):
+        self.orig = {n: getattr(self.mod, n) for n in self.names}
+        for n, f in self.orig.items():
+            setattr(self.mod, n, self._wrap(f))
+        return self
+
+    def _wrap(self, f):
+        def g(*a, **k):
+            self.n += 1
+            return f(*a, **k)
+        return g
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.mod, n, f)
+
+
+def qkv_loss(mods, x):
+    outs = [m(x) for m in mods]
+    return sum((o.float() * (i + 1)).square().mean() for i, o in enumerate(outs))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_shared_activation_quant_is_transparent(pkg, dtype):
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(0)
+    mods = [QuantizeLinear(512, 384, w_bits=4, a_bits=8).cuda().to(dtype) for _ in range(3)]
+    xs = torch.randn(2, 64, 512, device="cuda").to(dtype) * 1.5
+    res = {}
+    for share in (True, False):
+        pkg.share_activation_quant(share)
+        try:
+            x = xs.clone().requires_grad_(True)
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            with Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+                loss = qkv_loss(mods, x)
+            loss.backward()
+            res[share] = (loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n)
+        finally:
+            pkg.share_activation_quant(True)
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])                  # grad wrt the shared input: bit-identical
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[False][3] == 6 and res[True][3] == 4                  # 3 weights + 3 activations -> 3 weights + 1 activation
+
+
+def test_shared_activation_respects_inplace_and_identity(pkg):
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    m1, m2 = (QuantizeLinear(256, 64, w_bits=32, a_bits=8).cuda() for _ in range(2))
+    x = torch.randn(4, 256, device="cuda")
+    with torch.no_grad(), Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+        m1(x)
+        m2(x)                      # same tensor, same version -> shared
+        assert c.n == 1
+        x.mul_(2.0)                # version bump -> must recompute
+        m1(x)
+        assert c.n == 2
+        m2(x.clone())              # different tensor object -> must recompute
+        assert c.n == 3
+
+
+def test_weight_quant_cache_with_checkpoint(pkg):
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(QuantizeLinear(256, 512, w_bits=4, a_bits=8), torch.nn.SiLU(), QuantizeLinear(512, 256, w_bits=4, a_bits=8)).cuda().bfloat16()
+    with torch.no_grad():
+        net[0].weight[3, 5] = 2.5   # beyond the STE clip
+    xs = torch.randn(8, 256, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for cache in (False, True):
+        pkg.enable_weight_quant_cache(cache)
+        try:
+            net.zero_grad(set_to_none=True)
+            x = xs.clone().requires_grad_(True)
+            with Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+                out = checkpoint(net, x, use_reentrant=False)
+                out.float().square().mean().backward()
+            res[cache] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()], c.n)
+        finally:
+            pkg.enable_weight_quant_cache(False)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[True][2][0][3, 5] == 0                                 # STE mask still applied through the reuse node
+    assert res[False][3] == 8 and res[True][3] == 6                   # 2 x (2 weights + 2 acts) -> weights once
+    # an optimizer step changes the weights: the cache must not serve a stale copy
+    pkg.enable_weight_quant_cache(True)
+    try:
+        with torch.no_grad():
+            y1 = net(xs)
+            for p in net.parameters():
+                p.add_(0.01)
+            y2 = net(xs)
+        pkg.enable_weight_quant_cache(False)
+        with torch.no_grad():
+            y3 = net(xs)
+        assert torch.equal(y2, y3) and not torch.equal(y1, y2)
+    finally:
+        pkg.enable_weight_quant_cache(False)
+
+
+# ------------------------------------------------------------------------------------------ ABI claims
+def test_c_abi_calls_are_graph_capturable(pkg):
+    """no allocation / sync inside the library: a forward+backward pair captures into a hipGraph and replays"""
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    rows, cols = 512, 4096
+    x = torch.randn(rows, cols, device="cuda").bfloat16()
+    g = torch.randn(rows, cols, device="cuda").bfloat16()
+    y, gx = torch.empty_like(x), torch.empty_like(x)
+    bounds = torch.empty(rows, 2, device="cuda")
+    mbytes = L.fq_ste_mask_bytes(rows, cols, _lib.DTYPE_BF16)
+    mask = torch.empty(mbytes, dtype=torch.uint8, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            st = torch.cuda.current_stream().cuda_stream
+            assert L.fq_sym_fwd_train(x.data_ptr(), y.data_ptr(), rows, cols, 8, _lib.DTYPE_BF16, 0, -2.0, 2.0, bounds.data_ptr(),
+                                      mask.data_ptr(), mbytes, st) == 0
+            assert L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, -2.0, 2.0, bounds.data_ptr(), mask.data_ptr(), mbytes,
+                                     _lib.DTYPE_BF16, st) == 0
+    for trial in range(3):
+        x.copy_(torch.randn(rows, cols, device="cuda") * (trial + 1))
+        graph.replay()
+        torch.cuda.synchronize()
+        yo, _, _ = O.sym_fwd(np_from(x), rows, cols, 8, "bf16")
+        assert bits_equal(np_from(y), yo, "bf16")
+        assert bits_equal(np_from(gx), O.ste_bwd(np_from(g), np_from(x), -2.0, 2.0, "bf16"), "bf16")
+
+
+def test_concurrent_streams_and_threads(pkg):
+    """stateless + re-entrant: 4 host threads x own stream, interleaved launches, all results exact"""
+    import threading
+    from llm_qat_amd.utils_quant import SymQuantizer
+    errors = []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            gen = torch.Generator(device="cuda").manual_seed(seed)
+            with torch.cuda.stream(s):
+                for it in range(20):
+                    x = (torch.randn(256, 1024 + 8 * seed, generator=gen, device="cuda") * (0.02 if it % 2 else 1.5)).bfloat16().requires_grad_(True)
+                    y = SymQuantizer.apply(x, torch.tensor([-2.0, 2.0]), 4 + 4 * (it % 2), False)
+                    y.backward(torch.ones_like(y))
+                    s.synchronize()
+                    yo, _, _ = O.sym_fwd(np_from(x), 256, x.shape[1], 4 + 4 * (it % 2), "bf16")
+                    if not bits_equal(np_from(y), yo, "bf16"):
+                        errors.append((seed, it, "fwd"))
+                    want = O.ste_bwd(np_from(torch.ones_like(y)), np_from(x), -2.0, 2.0, "bf16")
+                    if not bits_equal(np_from(x.grad), want, "bf16"):
+                        errors.append((seed, it, "bwd"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]

@@ -110,3 +110,24 @@ def test_bf16_reciprocal_multiply_equals_divide_exhaustively():
         a = (idx[None, :] / t2[chunk, None]).astype(np.float32)
         b = (idx[None, :] * rinv[chunk, None]).astype(np.float32)
         assert (rb(a) == rb(b)).all()
+
+
+def test_w12_weight_branches_match_reference_fixtures():
+    """QuantizeLinear's 1-/2-bit weight branches: the value handed to F.linear (detach trick included),
+    given the reference's own mean-|w| scale, is reproduced bit for bit."""
+    G = golden("w12.npz")
+    assert len(G.cases) == 36
+    for c in G.cases:
+        dt, (rows, cols) = c["dtype"], c["shape"]
+        w, sc = G.arr(c, "w"), to_f32(G.arr(c, "scale"), c["dtype"])
+        if c["layerwise"]:
+            q, _ = O.w12_fwd(w.reshape(1, -1), 1, rows * cols, c["w_bits"], dt, scale_in=sc)
+            q = q.reshape(rows, cols)
+        else:
+            q, _ = O.w12_fwd(w, rows, cols, c["w_bits"], dt, scale_in=sc)
+        assert bits_equal(q, G.arr(c, "wq"), dt), f"{c['name']}: {mismatch_report(q, G.arr(c, 'wq'), dt)}"
+        # the oracle's own (double-precision) mean agrees with ATen's fp32 mean to within one ulp of the dtype
+        _, own = O.w12_fwd(w.reshape(1, -1) if c["layerwise"] else w, 1 if c["layerwise"] else rows, rows * cols if c["layerwise"] else cols, c["w_bits"], dt)
+        ok = np.isfinite(sc) & (sc != 0)
+        tol = {"fp32": 1e-6, "bf16": 8e-3, "fp16": 1e-3}[dt]
+        assert np.allclose(own[ok], sc[ok], rtol=tol), c["name"]

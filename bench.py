@@ -263,16 +263,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    device = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL; used for the timing barrier / max only -- no data-path collective
+        # The data path has no collective (replicas only).  The process group exists for the timing barrier and the
+        # max-over-ranks: RCCL ("nccl") as the launch contract says; BENCH_DIST_BACKEND=gloo keeps even that off the GPUs.
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        try:
+            dist.init_process_group(backend)
+            t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+        except Exception as e:  # noqa: BLE001
+            if backend != "nccl":
+                raise
+            print(f"bench.py: RCCL process group failed ({e!r}); using gloo for the timing barrier", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
     elif args.gpus > 1:
         print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE unset); running 1 rank",
               file=sys.stderr)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(device)
 
     wl = Workload(device)
     wl.prime_bounds()

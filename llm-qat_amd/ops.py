@@ -117,6 +117,72 @@ def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     return y, bounds, idx, scale
 
 
+# ---- lean path used by the autograd Functions: one side allocation (row bounds + STE mask), memoised sizes ----
+_mask_bytes_memo = {}
+
+
+def _mask_bytes(rows, cols, code):
+    k = (rows, cols, code)
+    v = _mask_bytes_memo.get(k)
+    if v is None:
+        v = _mask_bytes_memo[k] = _lib.lib().fq_ste_mask_bytes(rows, cols, code)
+    return v
+
+
+def train_forward(kind, x, num_bits, layerwise, lo, hi):
+    """-> (y, side, rows, cols) or None.  `side` is one uint8 buffer: float[rows][2] bounds followed by the mask."""
+    if x.device.type != "cuda":
+        _prep(x, f"{kind}_quantize")
+    code = _DTYPES.get(x.dtype)
+    if code is None:
+        _prep(x, f"{kind}_quantize")
+    if not x.is_contiguous() or x.numel() == 0:
+        return None
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    mbytes = _mask_bytes(rows, cols, code)
+    if not mbytes:
+        return None
+    L = _lib.lib()
+    y = torch.empty_like(x)
+    side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
+    sp = side.data_ptr()
+    fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
+    dev = x.device.index
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
+                    torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
+                torch.cuda.current_stream().cuda_stream)
+    if rc:
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, f"{kind}_quantize_train")
+    return y, side, rows, cols
+
+
+def train_backward(grad_output, side, rows, cols, lo, hi):
+    code = _DTYPES.get(grad_output.dtype)
+    if code is None or grad_output.device.type != "cuda":
+        _prep(grad_output, "ste_backward")
+    g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
+    gx = torch.empty_like(g)
+    sp = side.data_ptr()
+    dev = g.device.index
+    L = _lib.lib()
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code,
+                                   torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code,
+                               torch.cuda.current_stream().cuda_stream)
+    if rc:
+        _lib.check(rc, "ste_backward_mask")
+    return gx
+
+
 def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
     not served by the STE-mask path (the caller then uses the general forward + x-based backward)."""

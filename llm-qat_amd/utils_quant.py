@@ -44,6 +44,8 @@ def get_backward_mode():
 
 
 def _clip_pair(clip_val):
+    if clip_val is _CLIP:
+        return -2.0, 2.0
     lo, hi = clip_val.tolist()[:2] if clip_val.dim() else (clip_val.item(),) * 2
     return float(lo), float(hi)
 
@@ -55,16 +57,15 @@ class _FakeQuantFunction(torch.autograd.Function):
     def _fwd(kind, ctx, input, clip_val, num_bits, layerwise):
         mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
         ctx.fq_mode = "plain"
-        ctx.row_bounds = ctx.ste_mask = None
-        if mode != "plain":
+        ctx.row_bounds = None
+        if mode == "bounds":
             ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
         if mode == "mask":
             lo, hi = _clip_pair(clip_val)
-            res = ops.quantize_train(kind, input, num_bits, layerwise, lo, hi)
+            res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
             if res is not None:
-                out, ctx.row_bounds, ctx.ste_mask = res
-                ctx.fq_mode, ctx.clip = "mask", (lo, hi)
-                ctx.in_shape = input.shape
+                out, ctx.side, rows, cols = res
+                ctx.fq_mode, ctx.clip, ctx.rows_cols = "mask", (lo, hi), (rows, cols)
                 return out  # the input itself is not needed again
             mode = "bounds"
         ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
@@ -81,7 +82,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "mask":
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
-            return ops.ste_backward_mask(grad_output, lo, hi, ctx.row_bounds, ctx.ste_mask, rows, cols), None, None, None
+            return ops.train_backward(grad_output, ctx.side, rows, cols, lo, hi), None, None, None
         input, clip_val = ctx.saved_tensors  # reference :83 / :158
         lo, hi = _clip_pair(clip_val)
         bounds = ctx.row_bounds

@@ -153,7 +153,8 @@ class Workload:
         self.torch.cuda.synchronize()
 
     def time_kernel(self, fn, iters):
-        """average launch duration (ms) of one kernel kind, HIP events on the launch stream, rotating buffers"""
+        """Launch duration of one kernel kind with HIP events on the launch stream, rotating buffers.
+        -> (mean ms over a back-to-back batch, [p10, p50, p90] ms of individually bracketed launches)"""
         torch = self.torch
         for i in range(3):
             fn(self.sets[i % self.nsets])
@@ -164,14 +165,33 @@ class Workload:
             fn(self.sets[i % self.nsets])
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        mean = e0.elapsed_time(e1) / iters
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i, (a, b) in enumerate(pairs):
+            a.record()
+            fn(self.sets[i % self.nsets])
+            b.record()
+        torch.cuda.synchronize()
+        d = sorted(a.elapsed_time(b) for a, b in pairs)
+        return mean, [d[len(d) // 10], d[len(d) // 2], d[(9 * len(d)) // 10]]
 
 
-def roofline_entry(name, bytes_per_launch, ms, traffic=None):
+def roofline_entry(name, bytes_per_launch, timing, traffic=None):
+    """achieved = ALGORITHMIC bytes (4 B/elem forward, 6 B/elem backward, bf16) / launch time.
+    `traffic` = HBM bytes per launch measured with rocprofv3 --pmc (profiles/traffic.json); where the kernel moves
+    fewer bytes than the algorithmic figure (backward that does not re-read x) `frac` exceeds the byte-rate it
+    actually sustains, which is reported separately as traffic_gbs / traffic_frac."""
+    ms, pct = timing if isinstance(timing, tuple) else (timing, None)
     ach = bytes_per_launch / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(ms * 1e3, 2),
-            "algorithmic_bytes_per_launch": bytes_per_launch}
+    e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(ms * 1e3, 2),
+         "algorithmic_bytes_per_launch": bytes_per_launch}
+    if traffic:
+        e["traffic_gbs"] = round(traffic / (ms * 1e-3) / 1e9, 1)
+        e["traffic_frac"] = round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if pct:
+        e["us_p10_p50_p90"] = [round(v * 1e3, 2) for v in pct]
+    return e
 
 
 def load_traffic():
@@ -328,8 +348,8 @@ def main():
         }
         out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in alt.items()]
         dom = max(kernels, key=lambda e: e["us_per_launch"])
-        out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-        out["roofline"]["kernel"] = dom["kernel"]
+        out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic") if k in dom}
+        out["roofline"].update({k: dom[k] for k in ("kernel", "traffic_gbs", "traffic_frac", "us_per_launch") if k in dom})
         tot_us = sum(e["us_per_launch"] for e in kernels)
         out["roofline_step"] = {"bound": "hbm", "achieved": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -107,7 +107,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
         a.hi = host_rb(mk->hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool fast = !ASYM && bits <= 8;  // only honoured for bf16
+    const bool fast = bits <= 8;  // reciprocal-multiply instead of IEEE divide; only honoured for bf16
     switch (dtype) {
         case FQ_DTYPE_F32: return launch_rowwise<F32>(ASYM, fast, a, ws, wsb, st);
         case FQ_DTYPE_F16: return launch_rowwise<F16>(ASYM, fast, a, ws, wsb, st);

@@ -210,7 +210,7 @@ struct AsymConst {
     int mul_inv;  // 1 -> use invS
 };
 struct AsymRow {
-    float mn, al, a;
+    float mn, al, a, ra;
 };
 // utils_quant.py:116-124,:144: alpha = max - min ; beta = min ; a = alpha + 1e-8
 template <int DT> __device__ __forceinline__ AsymRow asym_row(float mx, float mn, AsymConst k) {
@@ -219,6 +219,7 @@ template <int DT> __device__ __forceinline__ AsymRow asym_row(float mx, float mn
     r.mn = mn;
     r.al = T::rb(mx - mn);
     r.a = T::rb(r.al + k.c8);
+    r.ra = 1.0f / r.a;  // only used by the bf16 FAST path
     return r;
 }
 
@@ -256,14 +257,18 @@ template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_dword(uint3
     return sym_chain<DT, FAST>(f, r, idx);
 }
 
-template <int DT>
+// FAST (bf16, bits <= 8): both IEEE divides become multiplies by a reciprocal.  Same argument as for Sym:
+// numerator and denominator have 8-bit significands (d = rb(x-beta) and a; idx <= 255 and S = 2^b-1), so the
+// exact quotient is never a bf16 rounding midpoint and lies >= 2^-17 (relative) away from one, while the
+// reciprocal-multiply error is < 2^-22.  Quotients below the bf16 normal range all round to bin 0 either way.
+template <int DT, bool FAST = false>
 __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const AsymRow& r, const AsymConst& k, int32_t* idx) {
     using T = Ty<DT>;
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] - r.mn;  // input - beta
     T::round_dt(f);
 #pragma unroll
-    for (int e = 0; e < T::EPD; ++e) f[e] = f[e] / r.a;  // / (alpha + 1e-8)
+    for (int e = 0; e < T::EPD; ++e) f[e] = FAST ? f[e] * r.ra : f[e] / r.a;  // / (alpha + 1e-8)
     T::round_dt(f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * k.S;  // * s
@@ -275,7 +280,7 @@ __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const As
         for (int e = 0; e < T::EPD; ++e) idx[e] = idx_i32(f[e]);
     }
 #pragma unroll
-    for (int e = 0; e < T::EPD; ++e) f[e] = k.mul_inv ? f[e] * k.invS : f[e] / k.S;  // .div(s)
+    for (int e = 0; e < T::EPD; ++e) f[e] = (FAST || k.mul_inv) ? f[e] * k.invS : f[e] / k.S;  // .div(s)
     T::round_dt(f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * r.a;  // * (alpha + 1e-8)
@@ -285,10 +290,11 @@ __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const As
     return T::pack(f);
 }
 
-template <int DT> __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
+template <int DT, bool FAST = false>
+__device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
     float f[Ty<DT>::EPD];
     Ty<DT>::unpack(w, f);
-    return asym_chain<DT>(f, r, k, idx);
+    return asym_chain<DT, FAST>(f, r, k, idx);
 }
 
 // QuantizeLinear's 1-/2-bit weight branches (utils_quant.py:203-242), forward value INCLUDING the

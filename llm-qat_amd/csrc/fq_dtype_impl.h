@@ -79,13 +79,12 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
 }
 
 template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st) {
-    if (asym) return rowwise_t<DT, true, false>(a, ws, wsb, st);
     if constexpr (DT == BF16) {
-        // bf16, Sym, <= 8 bits: the final divide becomes a multiply with the row's reciprocal --
-        // provably bit-identical after the bf16 rounding (DESIGN.md "Numerics").
-        if (fast) return rowwise_t<DT, false, true>(a, ws, wsb, st);
+        // bf16, <= 8 bits: the IEEE divides become multiplies with a reciprocal -- provably
+        // bit-identical after the bf16 rounding (DESIGN.md "Numerics").
+        if (fast) return asym ? rowwise_t<DT, true, true>(a, ws, wsb, st) : rowwise_t<DT, false, true>(a, ws, wsb, st);
     }
-    return rowwise_t<DT, false, false>(a, ws, wsb, st);
+    return asym ? rowwise_t<DT, true, false>(a, ws, wsb, st) : rowwise_t<DT, false, false>(a, ws, wsb, st);
 }
 
 template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {

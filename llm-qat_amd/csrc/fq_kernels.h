@@ -193,7 +193,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
             int32_t* ip = (DBG && idxr) ? ib + d * T::EPD : nullptr;
             if constexpr (!ASYM) o[d] = sym_chain<DT, FAST>(fd, sr, ip);
-            else o[d] = asym_chain<DT>(fd, ar, a.asym, ip);
+            else o[d] = asym_chain<DT, FAST>(fd, ar, a.asym, ip);
         }
         if (v < nvec) {
             st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
@@ -455,10 +455,10 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
                 o.z = sym_dword<DT, FAST>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
                 o.w = sym_dword<DT, FAST>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
             } else {
-                o.x = asym_dword<DT>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
-                o.y = asym_dword<DT>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
-                o.z = asym_dword<DT>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
-                o.w = asym_dword<DT>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
+                o.x = asym_dword<DT, FAST>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
+                o.y = asym_dword<DT, FAST>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
+                o.z = asym_dword<DT, FAST>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
+                o.w = asym_dword<DT, FAST>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
             }
             if (v < nvec) {
                 yr[v] = o;

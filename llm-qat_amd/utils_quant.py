@@ -58,8 +58,6 @@ class _FakeQuantFunction(torch.autograd.Function):
         mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
         ctx.fq_mode = "plain"
         ctx.row_bounds = None
-        if mode == "bounds":
-            ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
         if mode == "mask":
             lo, hi = _clip_pair(clip_val)
             res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
@@ -73,6 +71,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         if mode == "bounds":
             out, ctx.row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
             ctx.fq_mode = "bounds"
+            ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
         else:
             out = fn(input, num_bits, layerwise)
         return out

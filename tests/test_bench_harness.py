@@ -27,6 +27,8 @@ def test_aggregate_value_is_whole_job():
 def test_roofline_entry_math():
     e = bench.roofline_entry("k", 8_000_000_000, 1000.0)
     assert e["achieved"] == 8.0 and e["frac"] == 0.001 and e["peak"] == 8000.0 and e["bound"] == "hbm"
+    e = bench.roofline_entry("k", 8_000_000_000, (1000.0, [900.0, 1000.0, 1100.0]), traffic=4_000_000_000)
+    assert e["traffic_gbs"] == 4.0 and e["traffic_frac"] == 0.0005 and e["us_p10_p50_p90"] == [900000.0, 1000000.0, 1100000.0]
 
 
 WORKER = r"""

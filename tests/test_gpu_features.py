@@ -108,7 +108,7 @@ def test_shared_activation_quant_is_transparent(pkg, dtype):
             x = xs.clone().requires_grad_(True)
             for m in mods:
                 m.zero_grad(set_to_none=True)
-            with Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+            with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
                 loss = qkv_loss(mods, x)
             loss.backward()
             res[share] = (loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n)
@@ -125,7 +125,7 @@ def test_shared_activation_respects_inplace_and_identity(pkg):
     from llm_qat_amd.utils_quant import QuantizeLinear
     m1, m2 = (QuantizeLinear(256, 64, w_bits=32, a_bits=8).cuda() for _ in range(2))
     x = torch.randn(4, 256, device="cuda")
-    with torch.no_grad(), Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+    with torch.no_grad(), Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
         m1(x)
         m2(x)                      # same tensor, same version -> shared
         assert c.n == 1
@@ -149,7 +149,7 @@ def test_weight_quant_cache_with_checkpoint(pkg):
         try:
             net.zero_grad(set_to_none=True)
             x = xs.clone().requires_grad_(True)
-            with Counter(pkg.ops, ["quantize_train", "sym_quantize"]) as c:
+            with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
                 out = checkpoint(net, x, use_reentrant=False)
                 out.float().square().mean().backward()
             res[cache] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()], c.n)

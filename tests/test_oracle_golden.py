@@ -131,3 +131,56 @@ def test_w12_weight_branches_match_reference_fixtures():
         ok = np.isfinite(sc) & (sc != 0)
         tol = {"fp32": 1e-6, "bf16": 8e-3, "fp16": 1e-3}[dt]
         assert np.allclose(own[ok], sc[ok], rtol=tol), c["name"]
+
+
+def test_c_oracle_agrees_with_an_independent_numpy_restatement():
+    """Second, independently written restatement of the Sym recipe (vectorised numpy, fp32 ops + explicit
+    bf16 rounding) against the C oracle on random rows -- guards the oracle against a shared typo."""
+    rng = np.random.default_rng(123)
+
+    def rb(v):
+        u = np.ascontiguousarray(v, np.float32).view(np.uint32)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+        return r.view(np.float32)
+
+    for bits in (3, 4, 8):
+        x32 = (rng.standard_normal((200, 173)) * rng.choice([1e-6, 1e-3, 0.02, 1.0, 40.0], size=(200, 1))).astype(np.float32)
+        xb = (rb(x32).view(np.uint32) >> 16).astype(np.uint16)
+        x = (xb.astype(np.uint32) << 16).view(np.float32)
+        qmax = np.float32(2 ** (bits - 1) - 1)
+        c6 = rb(np.float32(1e-6))
+        m = np.abs(x).max(axis=1, keepdims=True)
+        s = rb(rb(np.float32(1.0) / rb(m + c6)) * qmax)
+        idx = np.rint(rb(x * s))
+        y = rb(idx / rb(s + c6))
+        yo, io, so = O.sym_fwd(xb, 200, 173, bits, "bf16")
+        assert (io == idx.astype(np.int32)).all()
+        assert ((y.view(np.uint32) >> 16).astype(np.uint16) == yo).all()
+        assert (so == s[:, 0]).all()
+
+
+def test_bf16_asym_reciprocal_multiplies_equal_divides():
+    """The bf16 <=8-bit Asym kernel replaces both IEEE divides by reciprocal multiplies:
+         n = rb(d * (1/a))  for  rb(d / a)      d = rb(x - beta), a = rb(alpha + 1e-8): 8-bit significands
+         w = rb(q * (1/S))  for  rb(q / S)      q in [0, 255], S = 2^bits - 1
+    Exhaustive over significand pairs (both operations are exactly scale-invariant in the normal range) and over
+    every (q, S)."""
+    def rb(v):
+        u = np.ascontiguousarray(v, np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    def bf16_range(lo_exp, hi_exp):          # every positive bf16 value in [2^lo_exp, 2^hi_exp)
+        bits = np.arange((127 + lo_exp) << 7, (127 + hi_exp) << 7, dtype=np.uint32)
+        return (bits << 16).view(np.float32)
+
+    d = bf16_range(-24, 1)                   # d <= ~a, down to 2^-24 * a
+    for a in (bf16_range(0, 1), bf16_range(-27, -26), bf16_range(100, 101)):
+        ra = (np.float32(1.0) / a).astype(np.float32)
+        dd = d * np.float32(a[0])            # same relative range at this exponent
+        exact = (dd[:, None] / a[None, :]).astype(np.float32)
+        fast = (dd[:, None] * ra[None, :]).astype(np.float32)
+        assert (rb(exact) == rb(fast)).all()
+    q = np.arange(0, 257, dtype=np.float32)
+    for bits in range(1, 9):
+        S = np.float32(2 ** bits - 1)
+        assert (rb(q / S) == rb(q * (np.float32(1.0) / S))).all()

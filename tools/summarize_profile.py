@@ -72,32 +72,52 @@ def main():
                 "read_bytes_corrected": statistics.median(kbf[name]) * 2 * 1024, "write_bytes": statistics.median(kbw.get(name, [0])) * 1024}
     bf, bw = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write"))
     traffic = {}
+
+    def split(vals):
+        """bimodal counter values -> (low cluster, high cluster); one cluster if the spread is < 1 %"""
+        lo, hi = min(vals), max(vals)
+        if hi - lo < 0.01 * hi:
+            return vals, []
+        cut = (lo + hi) / 2
+        return [v for v in vals if v < cut], [v for v in vals if v >= cut]
+
     for name in bf:
         if "fq::" not in name:
             continue
         fv, wv = bf[name], bw.get(name, [])
         entry = {"launches": len(fv)}
-        if "ste_rows" in name:  # bimodal: rows safe (g only) vs not (g and x)
-            cut = (min(fv) + max(fv)) / 2
-            for label, sel in (("rows_safe", [v for v in fv if v < cut]), ("rows_unsafe", [v for v in fv if v >= cut])):
-                if sel:
-                    rd = statistics.median(sel) * 2 * 1024
-                    wr = statistics.median(wv) * 1024 if wv else None
-                    entry[label] = {"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0), "launches": len(sel)}
-            if "rows_safe" in entry:
-                traffic["ste_bwd_w4"] = entry["rows_safe"]["total"]
-            if "rows_unsafe" in entry:
-                traffic["ste_bwd_a8"] = entry["rows_unsafe"]["total"]
+        f_lo, f_hi = split(fv)
+        w_lo, w_hi = split(wv) if wv else ([], [])
+        med = statistics.median
+        if "ste_rows" in name or "ste_mask" in name:
+            # bimodal on the READ side: rows provably unclipped (g only) vs rows that need x / the bit mask
+            wr = med(wv) * 1024 if wv else 0
+            entry["rows_safe"] = {"read_bytes": med(f_lo) * 2048, "write_bytes": wr, "total": med(f_lo) * 2048 + wr, "launches": len(f_lo)}
+            traffic["ste_bwd_w4"] = entry["rows_safe"]["total"]
+            if f_hi:
+                entry["rows_clippable"] = {"read_bytes": med(f_hi) * 2048, "write_bytes": wr, "total": med(f_hi) * 2048 + wr, "launches": len(f_hi)}
+                traffic["ste_bwd_a8"] = entry["rows_clippable"]["total"]
+        elif "row_reg_kernel" in name:
+            # bimodal on the WRITE side in training mode: the A8 leg also writes the 1-bit STE mask
+            rd = med(fv) * 2048
+            entry["no_mask_rows"] = {"read_bytes": rd, "write_bytes": med(w_lo) * 1024 if w_lo else None, "launches": len(w_lo)}
+            traffic["sym_fwd_w4"] = rd + (med(w_lo) * 1024 if w_lo else 0)
+            traffic["sym_fwd_a8"] = traffic["sym_fwd_w4"]
+            if w_hi:
+                entry["mask_rows"] = {"read_bytes": rd, "write_bytes": med(w_hi) * 1024, "launches": len(w_hi)}
+                traffic["sym_fwd_a8"] = rd + med(w_hi) * 1024
         else:
-            rd = statistics.median(fv) * 2 * 1024
-            wr = statistics.median(wv) * 1024 if wv else None
+            rd = med(fv) * 2048
+            wr = med(wv) * 1024 if wv else None
             entry.update({"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0)})
-            if "row_reg_kernel" in name:
-                traffic["sym_fwd_w4"] = traffic["sym_fwd_a8"] = entry["total"]
+            if "ste_vec_kernel" in name:
+                traffic["ste_bwd_a8_xread"] = entry["total"]
         d = dur.get(short(name))
         if d:
             entry["avg_duration_ns_unprofiled_trace"] = statistics.mean(d)
         res["kernels"][short(name)] = entry
+    if "sym_fwd_w4" in traffic:
+        traffic["sym_fwd_w4_plain"] = traffic["sym_fwd_w4"]
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))

@@ -10,11 +10,11 @@ namespace fq {
 // Launch shape of the register-resident kernel, from tools/kbench on MI355X: 2-3 vectors per
 // thread is the sweet spot (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
 // 4096 cols: 256 x 2 = 6.1 us, 128 x 4 = 6.3, 64 x 8 = 6.9, 512 x 1 = 7.7).
-template <int DT, bool ASYM, bool FAST, bool NT, bool DBG>
+template <int DT, bool ASYM, bool FAST, bool NTL, bool NTS, bool DBG>
 static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #define R(TPR, V)                                                                                                   \
     case V:                                                                                                         \
-        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NT, NT, DBG>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),   \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NTL, NTS, DBG>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows), \
                   (TPR == 64 ? 256 : TPR), st, a);                                                                  \
         break;
     if (nvec <= 192) {
@@ -37,15 +37,17 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     constexpr int EPV = 16 / T::ESIZE;
     const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0);
     const int64_t nvec = a.cols / EPV;
-    const bool nt = a.rows * a.cols * T::ESIZE >= NT_MIN_BYTES;
+    const int64_t bytes = a.rows * a.cols * T::ESIZE;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
     bool two_pass = false, two_pass_vec = false;
     if (vec_ok && nvec <= REG_MAX_VEC) {
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
         // the diagnostic outputs (bin indices, scales) live in their own instantiation so the product
         // kernels carry none of that code; it runs the same arithmetic with the default cache policy
-        if (a.idx || a.scale) launch_reg<DT, ASYM, FAST, false, true>(a, nvec, st);
-        else if (nt) launch_reg<DT, ASYM, FAST, true, false>(a, nvec, st);
-        else launch_reg<DT, ASYM, FAST, false, false>(a, nvec, st);
+        if (a.idx || a.scale) launch_reg<DT, ASYM, FAST, false, false, true>(a, nvec, st);
+        else if (ntl) launch_reg<DT, ASYM, FAST, true, true, false>(a, nvec, st);
+        else if (nts) launch_reg<DT, ASYM, FAST, false, true, false>(a, nvec, st);
+        else launch_reg<DT, ASYM, FAST, false, false, false>(a, nvec, st);
     } else if (a.mask) {
         return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
     } else if (vec_ok) {
@@ -94,10 +96,13 @@ template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t
         const int64_t nvec = n / EPV;
         const int64_t grid = (nvec + STE_THREADS - 1) / STE_THREADS;  // one vector per thread measured best (kbench)
         if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "n too large");
-        if (n * T::ESIZE >= NT_MIN_BYTES)
-            FQ_LAUNCH((ste_vec_kernel<DT, 1, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+        const int64_t bytes = n * T::ESIZE;
+        if (bytes >= NT_LOAD_MIN_BYTES)
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, true, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+        else if (bytes >= NT_STORE_MIN_BYTES)
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, false, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
         else
-            FQ_LAUNCH((ste_vec_kernel<DT, 1, false>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, false, false>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
     } else {
         int64_t grid = (n + STE_THREADS - 1) / STE_THREADS;
         if (grid > 8192) grid = 8192;
@@ -121,11 +126,13 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     const int cv = (int)((nvec_row + chunks - 1) / chunks);
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
     if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-    const bool nt = rows * cols * T::ESIZE >= NT_MIN_BYTES;
-#define S(V)                                                                                                                       \
-    case V:                                                                                                                        \
-        if (nt) FQ_LAUNCH((ste_rows_kernel<DT, V, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);  \
-        else FQ_LAUNCH((ste_rows_kernel<DT, V, false>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);   \
+    const int64_t bytes = rows * cols * T::ESIZE;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
+#define S(V)                                                                                                                              \
+    case V:                                                                                                                               \
+        if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);        \
+        else if (nts) FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);  \
+        else FQ_LAUNCH((ste_rows_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);          \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -147,11 +154,13 @@ int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
     cv = (cv + 63) / 64 * 64;  // every wave covers exactly one 64-vector mask group per slot
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
     if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-    const bool nt = rows * cols * T::ESIZE >= NT_MIN_BYTES;
-#define S(V)                                                                                                                            \
-    case V:                                                                                                                             \
-        if (nt) FQ_LAUNCH((ste_mask_kernel<DT, V, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi); \
-        else FQ_LAUNCH((ste_mask_kernel<DT, V, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);   \
+    const int64_t bytes = rows * cols * T::ESIZE;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
+#define S(V)                                                                                                                                    \
+    case V:                                                                                                                                     \
+        if (ntl) FQ_LAUNCH((ste_mask_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);        \
+        else if (nts) FQ_LAUNCH((ste_mask_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);  \
+        else FQ_LAUNCH((ste_mask_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);          \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S

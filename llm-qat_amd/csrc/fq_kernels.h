@@ -486,7 +486,7 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
 // ------------------------------------------------------------------------------------
 constexpr int STE_THREADS = 256;
 
-template <int DT, int UNR, bool NT = true>
+template <int DT, int UNR, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __restrict__ g, const uint4* __restrict__ x,
                                                               uint4* __restrict__ gx, int64_t nvec, float lo, float hi) {
     const int64_t v0 = (int64_t)blockIdx.x * (STE_THREADS * UNR) + threadIdx.x;
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __res
     for (int i = 0; i < UNR; ++i) {
         int64_t v = v0 + (int64_t)i * STE_THREADS;
         v = v < nvec ? v : nvec - 1;
-        rg[i] = ld16<NT>(&g[v]);
-        rx[i] = ld16<NT>(&x[v]);
+        rg[i] = ld16<NTL>(&g[v]);
+        rx[i] = ld16<NTL>(&x[v]);
     }
 #pragma unroll
     for (int i = 0; i < UNR; ++i) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_vec_kernel(const uint4* __res
         o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
         o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
         o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
-        if (v < nvec) st16<NT>(&gx[v], o);
+        if (v < nvec) st16<NTS>(&gx[v], o);
     }
 }
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_scalar_kernel(const void* __r
 // Row-aware STE: block b handles chunk (b % chunks) of row (b / chunks); a chunk is `cv` vectors
 // (cv <= STE_THREADS * VPT; the host balances chunks so no block is nearly empty).  If the row's
 // recorded bounds are strictly inside (lo, hi) no element can be masked: copy g, never touch x.
-template <int DT, int VPT, bool NT = true>
+template <int DT, int VPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __restrict__ g, const void* __restrict__ x,
                                                                void* __restrict__ gx, int64_t nvec_row, int64_t chunks, int cv,
                                                                const float* __restrict__ bounds, float lo, float hi) {
@@ -546,13 +546,13 @@ __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __res
     for (int i = 0; i < VPT; ++i) {
         int v = t + i * STE_THREADS;
         v = v < nvec ? v : nvec - 1;
-        rg[i] = ld16<NT>(&gr[v]);
+        rg[i] = ld16<NTL>(&gr[v]);
     }
     if (safe) {  // block-uniform
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = t + i * STE_THREADS;
-            if (v < nvec) st16<NT>(&or_[v], rg[i]);
+            if (v < nvec) st16<NTS>(&or_[v], rg[i]);
         }
     } else {
         uint4 rx[VPT];
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __res
         for (int i = 0; i < VPT; ++i) {
             int v = t + i * STE_THREADS;
             v = v < nvec ? v : nvec - 1;
-            rx[i] = ld16<NT>(&xr[v]);
+            rx[i] = ld16<NTL>(&xr[v]);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __res
             o.y = ste_dword<DT>(rg[i].y, rx[i].y, lo, hi);
             o.z = ste_dword<DT>(rg[i].z, rx[i].z, lo, hi);
             o.w = ste_dword<DT>(rg[i].w, rx[i].w, lo, hi);
-            if (v < nvec) st16<NT>(&or_[v], o);
+            if (v < nvec) st16<NTS>(&or_[v], o);
         }
     }
 }
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
 // clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
 // every wave covers exactly one mask group per slot.
-template <int DT, int VPT, bool NT = true>
+template <int DT, int VPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nvec_row,
                                                                int64_t chunks, int cv, const float* __restrict__ bounds,
                                                                const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
@@ -635,13 +635,13 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
     for (int i = 0; i < VPT; ++i) {
         int v = t + i * STE_THREADS;
         v = v < nvec ? v : nvec - 1;
-        rg[i] = ld16<NT>(&gr[v]);
+        rg[i] = ld16<NTL>(&gr[v]);
     }
     if (safe) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = t + i * STE_THREADS;
-            if (v < nvec) st16<NT>(&or_[v], rg[i]);
+            if (v < nvec) st16<NTS>(&or_[v], rg[i]);
         }
     } else {
         const uint64_t* mrow = mask + row * mask_row_words;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
 #pragma unroll
             for (int e = 0; e < EPV; ++e) mw[e] = mrow[grp * EPV + e];  // wave-uniform address -> scalar loads
             const uint4 o = ste_mask_apply<DT>(rg[i], mw, (int)((vs + v) & 63));
-            if (v < nvec) st16<NT>(&or_[v], o);
+            if (v < nvec) st16<NTS>(&or_[v], o);
         }
     }
 }

@@ -18,10 +18,14 @@ FQ_HIDDEN int ok();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Tensors at least this large cannot stay in the 32 MiB of L2 anyway: stream them with the
-// non-temporal policy (+7..9 % on the 90 MB metric tensor).  Smaller ones keep the default
-// policy so the consumer (the GEMM that follows) can still find them in L2 / Infinity Cache.
-constexpr int64_t NT_MIN_BYTES = 32ll << 20;
+// Cache policy of the 16-byte streams, from tools/kbench on MI355X (every tensor is touched once per launch):
+//  * stores: non-temporal from 4 MiB up (a tensor that size cannot stay in an XCD's 4 MiB L2 anyway).  NT stores
+//    win at every size measured: 16 MB forward 7.3 -> 5.9 us, 45 MB 17.9 -> 14.2 us, 90 MB 34.3 -> 31.9 us.
+//  * loads: non-temporal only from 64 MiB up.  Below that the input was typically produced by the kernel just
+//    before and still sits in the 256 MiB Infinity Cache, where plain loads are faster (16 MB: 5.9 vs 6.1 us,
+//    45 MB: 14.2 vs 16.1 us); the big MLP weights come from HBM, where NT loads are faster (90 MB: 31.1 vs 31.9 us).
+constexpr int64_t NT_STORE_MIN_BYTES = 4ll << 20;
+constexpr int64_t NT_LOAD_MIN_BYTES = 64ll << 20;
 
 constexpr int64_t REG_MAX_VEC = 1024 * 8;    // longest row (in 16-byte vectors) the register kernels hold
 constexpr int64_t GENERIC_MAX_COLS = 32768;  // longest row the scalar-load kernel sweeps

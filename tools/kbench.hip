@@ -244,16 +244,17 @@ int main(int argc, char** argv) {
                time_it([&](int i) { launch_sym<TPR, VPT, FAST, NTL, NTS>(b.x[i % NS], b.y[i % NS], b.bounds[i % NS], rows, cols, 4); }, IT));
     SYM(256, 6, true, false, false) SYM(256, 6, true, true, false) SYM(256, 6, true, false, true) SYM(256, 6, true, true, true)
     SYM(512, 3, true, false, false) SYM(512, 3, true, true, true) SYM(1024, 2, true, true, true) SYM(256, 6, false, true, true)
-    SYM(256, 2, true, false, false) SYM(256, 2, true, true, true) SYM(128, 4, true, true, true) SYM(64, 8, true, true, true) SYM(512, 1, true, true, true)
+    SYM(256, 2, true, false, false) SYM(256, 2, true, true, true) SYM(256, 2, true, true, false) SYM(256, 2, true, false, true) SYM(128, 4, true, true, true) SYM(64, 8, true, true, true) SYM(512, 1, true, true, true)
     SYM(256, 7, true, true, true) SYM(512, 4, true, true, true)
 
     // ---- STE backward variants
-#define STE(U, NT)                                                                                                                  \
-    report("ste_vec<UNR=" #U ",NT=" #NT ">", 3.0 * bytes, time_it([&](int i) {                                                      \
-               hipLaunchKernelGGL((ste_vec_kernel<BF16, U, NT>), dim3((unsigned)((nvec + STE_THREADS * U - 1) / (STE_THREADS * U))), \
+#define STE(U, NT)  STE2(U, NT, NT)
+#define STE2(U, NTL, NTS)                                                                                                           \
+    report("ste_vec<UNR=" #U ",NTL=" #NTL ",NTS=" #NTS ">", 3.0 * bytes, time_it([&](int i) {                                       \
+               hipLaunchKernelGGL((ste_vec_kernel<BF16, U, NTL, NTS>), dim3((unsigned)((nvec + STE_THREADS * U - 1) / (STE_THREADS * U))), \
                                   dim3(STE_THREADS), 0, 0, (const uint4*)b.g[i % NS], (const uint4*)b.x[i % NS], (uint4*)b.gx[i % NS], nvec, -2.0f, 2.0f); \
            }, IT));
-    STE(1, false) STE(1, true) STE(2, true) STE(4, true)
+    STE(1, false) STE(1, true) STE2(1, false, true) STE2(1, true, false) STE(2, true) STE(4, true)
     // row-bounds variant: bounds were written by the sym launches above (weights: every row safe)
     {
         const int64_t chunks = (nv_row + 256 * 8 - 1) / (256 * 8);
@@ -263,9 +264,16 @@ int main(int argc, char** argv) {
 #define STER(V, NT, LO, HI, LABEL)                                                                                                    \
     if (vpt == V)                                                                                                                     \
         report("ste_rows<VPT=" #V ",NT=" #NT "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                            \
-                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, NT>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
+                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, NT, NT>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
                                       b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI);                       \
                }, IT));
+#define STERM(V, LO, HI, LABEL)                                                                                                      \
+    if (vpt == V)                                                                                                                     \
+        report("ste_rows<VPT=" #V ",NTL=0,NTS=1> " LABEL, 3.0 * bytes, time_it([&](int i) {                                          \
+                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, false, true>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI);                       \
+               }, IT));
+        STERM(6, -2.0f, 2.0f, "all rows safe") STERM(6, -1e-3f, 1e-3f, "no row safe") STERM(2, -2.0f, 2.0f, "all rows safe") STERM(2, -1e-3f, 1e-3f, "no row safe")
         STER(6, false, -2.0f, 2.0f, "all rows safe") STER(6, true, -2.0f, 2.0f, "all rows safe")
         STER(6, false, -1e-3f, 1e-3f, "no row safe") STER(6, true, -1e-3f, 1e-3f, "no row safe")
         // forced small chunks: cv = 256 / 512 vectors per block
@@ -273,7 +281,7 @@ int main(int argc, char** argv) {
     {                                                                                                                                 \
         const int64_t ch2 = (nv_row + CV - 1) / CV;                                                                                   \
         report("ste_rows<VPT=" #V ",NT=1,cv=" #CV "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                        \
-                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, true>), dim3((unsigned)(rows * ch2)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
+                   hipLaunchKernelGGL((ste_rows_kernel<BF16, V, true, true>), dim3((unsigned)(rows * ch2)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
                                       b.x[i % NS], b.gx[i % NS], nv_row, ch2, CV, b.bounds[i % NS], LO, HI);                          \
                }, IT));                                                                                                               \
     }

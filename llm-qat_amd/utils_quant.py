@@ -78,6 +78,7 @@ class _FakeQuantFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
         if ctx.fq_mode == "mask":
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
@@ -131,16 +132,19 @@ _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every
 #    last (input -> output) pair per thread and hands the same output (and autograd node) to the
 #    sibling projections.  Gradients are unchanged bit for bit: the STE mask is applied once to the
 #    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum.
-#    A hit requires the very same tensor object at the same version; the remembered output is released as
-#    soon as that input tensor dies (weak reference + callback), so nothing outlives the caller's own use.
+#    A hit requires the very same tensor object at the same version and that no fake-quant backward has run
+#    since (so an output whose graph was already consumed is never handed out again); the remembered output is
+#    released as soon as that input tensor dies (weak reference + callback).
 # 2. Under activation checkpointing every weight is fake-quantized twice per step (first forward, then
 #    the recompute -- reentrant or not) although it has not changed.  With the weight cache on (opt-in:
 #    it keeps one quantized copy per layer alive from the first use until the second), the second use
 #    within a step reuses the first result.  The key holds the parameter's identity, version counter and
 #    storage address, so an optimizer step / load_state_dict / .data swap can never be served stale.
 # ---------------------------------------------------------------------------------------------
+_bwd_epoch = [0]
 _SHARE_ACT = os.environ.get("LLMQAT_AMD_SHARE_ACT", "1") != "0"
-_WEIGHT_CACHE = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") == "1"
+_WEIGHT_CACHE = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") in ("1", "persistent")
+_WEIGHT_CACHE_PERSISTENT = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") == "persistent"
 _tls = threading.local()
 
 
@@ -149,9 +153,13 @@ def share_activation_quant(flag=True):
     _SHARE_ACT = bool(flag)
 
 
-def enable_weight_quant_cache(flag=True):
-    global _WEIGHT_CACHE
+def enable_weight_quant_cache(flag=True, persistent=False):
+    """flag: reuse a weight's fake-quantized value for its second use within a step (checkpoint recompute).
+    persistent: keep it until the weight itself changes (optimizer step), so gradient-accumulation micro-batches
+    reuse it too -- costs one quantized copy per layer for the whole run."""
+    global _WEIGHT_CACHE, _WEIGHT_CACHE_PERSISTENT
     _WEIGHT_CACHE = bool(flag)
+    _WEIGHT_CACHE_PERSISTENT = bool(flag) and bool(persistent)
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
@@ -163,8 +171,8 @@ def _shared_activation(quantizer, x, num_bits, layerwise):
     key = (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics())
     ent = cache.get(key)
     if ent is not None:
-        rin, ver_in, y, ver_out = ent
-        if rin() is x and ver_in == x._version and ver_out == y._version:
+        rin, ver_in, y, ver_out, epoch = ent
+        if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0]:
             return y
     y = quantizer.apply(x, _CLIP, num_bits, layerwise)
 
@@ -173,7 +181,7 @@ def _shared_activation(quantizer, x, num_bits, layerwise):
         if ent is not None and ent[0] is ref:
             del cache[key]
 
-    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version)
+    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0])
     return y
 
 
@@ -230,7 +238,8 @@ class QuantizeLinear(nn.Linear):
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:
             cached = ent[1]
-            self._fq_wcache = None  # second use within the step (the checkpoint recompute): done with it
+            if not _WEIGHT_CACHE_PERSISTENT:
+                self._fq_wcache = None  # second use within the step (the checkpoint recompute): done with it
         else:
             rc = ops.rows_cols(tuple(w.shape), self.weight_layerwise)
             res = ops.quantize_train("sym", w, self.w_bits, self.weight_layerwise, -2.0, 2.0) if _BACKWARD_MODE == "mask" else None

@@ -136,6 +136,25 @@ def test_shared_activation_respects_inplace_and_identity(pkg):
         assert c.n == 3
 
 
+def test_shared_activation_not_reused_across_training_steps(pkg):
+    """the same input OBJECT fed again after a backward must get a fresh autograd node (bounds/plain modes free
+    their saved tensors in backward; a stale shared node would raise or, worse, go unnoticed)"""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    for mode in ("mask", "bounds", "plain"):
+        pkg.set_backward_mode(mode)
+        try:
+            m1, m2 = (QuantizeLinear(256, 64, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(2))
+            x = (torch.randn(8, 256, device="cuda") * 1.5).bfloat16().requires_grad_(True)
+            grads = []
+            for step in range(3):
+                x.grad = None
+                (m1(x).float().square().mean() + m2(x).float().square().mean()).backward()
+                grads.append(x.grad.clone())
+            assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2]), mode
+        finally:
+            pkg.set_backward_mode("mask")
+
+
 def test_weight_quant_cache_with_checkpoint(pkg):
     from llm_qat_amd.utils_quant import QuantizeLinear
     torch.manual_seed(1)
@@ -160,11 +179,29 @@ def test_weight_quant_cache_with_checkpoint(pkg):
         assert torch.equal(a, b)
     assert res[True][2][0][3, 5] == 0                                 # STE mask still applied through the reuse node
     assert res[False][3] == 8 and res[True][3] == 6                   # 2 x (2 weights + 2 acts) -> weights once
+    # persistent mode: gradient-accumulation micro-batches reuse the weight until it changes
+    pkg.enable_weight_quant_cache(True, persistent=True)
+    try:
+        net.zero_grad(set_to_none=True)
+        with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
+            for micro in range(3):
+                checkpoint(net, xs.clone().requires_grad_(True), use_reentrant=False).float().square().mean().backward()
+        assert c.n == 2 + 3 * 2 * 2                                     # 2 weights once + activations every pass
+        g_persist = [p.grad.clone() for p in net.parameters()]
+        pkg.enable_weight_quant_cache(False)
+        net.zero_grad(set_to_none=True)
+        for micro in range(3):
+            checkpoint(net, xs.clone().requires_grad_(True), use_reentrant=False).float().square().mean().backward()
+        for a, b in zip(g_persist, [p.grad for p in net.parameters()]):
+            assert torch.equal(a, b)
+    finally:
+        pkg.enable_weight_quant_cache(False)
     # an optimizer step changes the weights: the cache must not serve a stale copy
     pkg.enable_weight_quant_cache(True)
     try:
         with torch.no_grad():
             y1 = net(xs)
+            net(xs)
             for p in net.parameters():
                 p.add_(0.01)
             y2 = net(xs)

@@ -381,3 +381,51 @@ def test_device_eager_semantics_vs_live_aten(ops, dtype):
         assert not bad, "\n".join(bad[:20])
     finally:
         llm_qat_amd.set_semantics("cpu_eager")
+
+
+# ------------------------------------------------------------------------------------------
+# randomized stress: shapes, dtypes, bits, clips, NaN/Inf injection -- every data flow vs the oracle
+# ------------------------------------------------------------------------------------------
+def test_randomized_stress_all_paths(ops):
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
+    rng = np.random.default_rng(20261004)
+    col_choices = [1, 3, 8, 24, 64, 100, 256, 264, 512, 1000, 1024, 2048, 4096, 4104, 8192, 11008, 16384, 20000]
+    prev = llm_qat_amd.get_backward_mode()
+    try:
+        for trial in range(120):
+            dtype = ["bf16", "fp32", "fp16"][trial % 3]
+            kind = "sym" if rng.random() < 0.6 else "asym"
+            rows, cols = int(rng.integers(1, 40)), int(rng.choice(col_choices))
+            bits = int(rng.choice([2, 3, 4, 6, 8, 12, 16])) if kind == "sym" else int(rng.choice([1, 2, 4, 8, 16]))
+            layerwise = bool(rng.random() < 0.15)
+            x = rng.standard_normal((rows, cols)).astype(np.float32) * rng.choice([1e-4, 0.02, 1.0, 3.0, 100.0], size=(rows, 1)).astype(np.float32)
+            if rng.random() < 0.3:
+                x[rng.integers(0, rows), rng.integers(0, cols)] = rng.choice([np.nan, np.inf, -np.inf])
+            if rng.random() < 0.3:
+                x[rng.integers(0, rows)] = 0.0
+            lo, hi = [(-2.0, 2.0), (-0.5, 0.75), (-1.0, 1.0), (-0.3009, 0.3009)][int(rng.integers(0, 4))]
+            xt = torch.from_numpy(x).to(TD[dtype])
+            x_np, xd = np_from(xt), xt.cuda()
+            g_np, gd = make_input(rng, (rows, cols), dtype, "act")
+            r, c = O.rows_cols((rows, cols), layerwise)
+            if kind == "sym":
+                yo, io, _ = O.sym_fwd(x_np, r, c, bits, dtype)
+                dbg, quant = ops.sym_quantize_debug, SymQuantizer
+            else:
+                yo, io, _, _ = O.asym_fwd(x_np, r, c, bits, dtype)
+                dbg, quant = ops.asym_quantize_debug, AsymQuantizer
+            want_g = O.ste_bwd(g_np, x_np, lo, hi, dtype)
+            tag = f"trial {trial}: {kind} {dtype} [{rows},{cols}] b{bits} lw={layerwise} clip=({lo},{hi})"
+            y, idx, _ = dbg(xd, bits, layerwise)
+            assert (np_from(idx) == io).all(), tag + " idx"
+            assert bits_equal(np_from(y), yo, dtype), tag + " y: " + mismatch_report(np_from(y), yo, dtype)
+            for mode in ("mask", "bounds", "plain"):
+                llm_qat_amd.set_backward_mode(mode)
+                xr = xd.clone().requires_grad_(True)
+                out = quant.apply(xr, torch.tensor([lo, hi]), bits, layerwise)
+                out.backward(gd)
+                assert bits_equal(np_from(out), yo, dtype), f"{tag} {mode} fwd"
+                assert bits_equal(np_from(xr.grad), want_g, dtype), f"{tag} {mode} grad: " + mismatch_report(np_from(xr.grad), want_g, dtype)
+    finally:
+        llm_qat_amd.set_backward_mode(prev)

@@ -228,6 +228,7 @@ def cpu_baseline(budget_s=15.0):
         if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 50:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
+    med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
     cores = torch.get_num_threads()
     model = ""
     try:
@@ -240,7 +241,8 @@ def cpu_baseline(budget_s=15.0):
     return {"value": round(2 * ROWS * COLS / best / 1e9, 4), "unit": "Gelem/s", "cores": cores, "kind": "port",
             "sample": f"full step (W4 + A8 fwd+bwd on [4096,11008] bf16), {len(times)} repeats, best of all but the first; "
                       f"eager ATen op chain restating models/utils_quant.py (bit-equal to the reference on CPU)",
-            "host_cpu": model, "host_logical_cpus": os.cpu_count(), "seconds_best": round(best, 4)}
+            "host_cpu": model, "host_logical_cpus": os.cpu_count(), "seconds_best": round(best, 4), "seconds_median": round(med, 4),
+            "value_median": round(2 * ROWS * COLS / med / 1e9, 4)}
 
 
 def gpu_eager(wl, iters=5):

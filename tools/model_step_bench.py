@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Whole-model QAT step (forward + backward, KD-style loss on logits) of an N-layer LLaMA with LLaMA-7B layer
+dimensions on one MI355X: the harness model (tests/tiny_llama.py, the reference's call sites) driven by
+  (a) the reference's eager fake-quant op chain, (b) this package's HIP-backed drop-in,
+optionally under activation checkpointing (as run_train.sh does) and with the weight cache.
+
+    python tools/model_step_bench.py [--layers 2] [--iters 8]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from torch.utils.checkpoint import checkpoint  # noqa: E402
+
+import tiny_llama as TL  # noqa: E402
+
+
+def build(quant, layers, wb, ab, kvb):
+    cfg = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=layers, num_attention_heads=32,
+               max_position_embeddings=2048, rms_norm_eps=1e-6)
+    torch.manual_seed(0)
+    m = TL.TinyLlama(quant, cfg=cfg, w_bits=wb, a_bits=ab, kv_bits=kvb).bfloat16().cuda()
+    return m
+
+
+def step(model, ids, ckpt):
+    model.zero_grad(set_to_none=True)
+    h = model.model.embed_tokens(ids)
+    for layer in model.model.layers:
+        h = checkpoint(layer, h, use_reentrant=False) if ckpt else layer(h)
+    logits = model.lm_head(model.model.norm(h))
+    loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), ids[..., 1:].reshape(-1))
+    loss.backward()
+    return loss
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=8)
+    args = ap.parse_args()
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+
+    class NoQuant:  # fp baseline: plain linears
+        SymQuantizer = None
+
+        @staticmethod
+        def QuantizeLinear(i, o, bias=False, w_bits=32, a_bits=32):
+            return torch.nn.Linear(i, o, bias=False)
+
+    ids = torch.randint(2, 32000, (1, 2048), device="cuda")
+    rows = []
+    for wb, ab, kvb in ((4, 8, 4), (8, 8, 8)):
+        for ckpt in (False, True):
+            for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
+                                         ("llm_qat_amd", UQ, False), ("llm_qat_amd + weight cache", UQ, True)):
+                if quant is NoQuant:
+                    model = build(quant, args.layers, 32, 32, 32)
+                else:
+                    model = build(quant, args.layers, wb, ab, kvb)
+                llm_qat_amd.enable_weight_quant_cache(wcache)
+                ms = timed(lambda: step(model, ids, ckpt), args.iters)
+                llm_qat_amd.enable_weight_quant_cache(False)
+                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, impl=label, ms_per_step=round(ms, 2), layers=args.layers))
+                print(rows[-1], flush=True)
+                del model
+                torch.cuda.empty_cache()
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "model_step_bench.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,12 +1,15 @@
 // fq_kernels.h -- the gfx950 kernels of the fake-quant hot path.
 //
-//   row_reg_kernel      one row per wave (TPR=64) or per workgroup (TPR=256/1024); the whole row
+//   row_reg_kernel      one row per wave (TPR=64) or per workgroup (TPR=128..1024); the whole row
 //                       is loaded ONCE with 16-byte global loads and stays in VGPRs across the
 //                       reduce -> scale -> round -> dequant sequence.  HBM traffic = read x + write y.
+//                       Training mode also records per-row bounds and a 1-bit/element STE mask.
 //   row_generic_kernel  any alignment / odd widths: element loads, two sweeps (2nd sweep is L2-hot).
 //   stats / apply       two-pass path for rows too long for registers (layerwise = one row).
-//   ste_kernel          straight-through-estimator mask, pure streaming.
+//   ste_mask_kernel     STE backward from (bounds, mask): reads g (+ mask), never x.
+//   ste_vec_kernel      STE backward re-reading x (the reference's data flow), pure streaming.
 //   ste_rows_kernel     same, but skips the x read for rows whose recorded bounds lie inside the clip.
+//   w12_kernel          elementwise part of QuantizeLinear's 1-/2-bit weight branches.
 //
 // Roofline for all of them: HBM bandwidth (<= ~10 VALU ops per element, no MFMA).
 #pragma once

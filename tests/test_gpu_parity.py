@@ -296,6 +296,9 @@ def test_error_behaviour_matches_reference(ops):
         SymQuantizer.apply(torch.zeros(4, 4, device="cuda", dtype=torch.float64), clip, 8, False)
     e = SymQuantizer.apply(torch.zeros(0, 8, device="cuda"), clip, 8, False)
     assert e.shape == (0, 8)
+    z = SymQuantizer.apply(torch.tensor(1.5, device="cuda"), clip, 8, False)      # 0-dim: one row of one element
+    yo, _, _ = O.sym_fwd(np.array([1.5], np.float32), 1, 1, 8, "fp32")
+    assert z.shape == () and float(z) == float(yo[0])
 
 
 # ------------------------------------------------------------------------------------------

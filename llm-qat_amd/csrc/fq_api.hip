@@ -107,7 +107,10 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
         a.hi = host_rb(mk->hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool fast = bits <= 8;  // reciprocal-multiply instead of IEEE divide; only honoured for bf16
+    // reciprocal-multiply instead of IEEE divide (only honoured for bf16).  Sym: valid for every bit width, because
+    // the bin index is rint() of a bf16 value and so has an 8-bit significand itself; Asym: the divisor 2^bits-1 must
+    // have one too, i.e. bits <= 8.
+    const bool fast = ASYM ? bits <= 8 : true;
     switch (dtype) {
         case FQ_DTYPE_F32: return launch_rowwise<F32>(ASYM, fast, a, ws, wsb, st);
         case FQ_DTYPE_F16: return launch_rowwise<F16>(ASYM, fast, a, ws, wsb, st);

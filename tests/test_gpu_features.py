@@ -276,3 +276,31 @@ def test_concurrent_streams_and_threads(pkg):
     for t in ts:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_python_level_graph_capture(pkg):
+    """the autograd Functions allocate only through PyTorch's (graph-safe) allocator and never synchronise:
+    a forward+backward captures into a CUDA/HIP graph and replays with fresh data"""
+    from llm_qat_amd.utils_quant import SymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    x = (torch.randn(512, 4096, device="cuda") * 1.5).bfloat16().requires_grad_(True)
+    g = torch.randn(512, 4096, device="cuda").bfloat16()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):   # warm the allocator / lazy inits outside the capture
+            SymQuantizer.apply(x, clip, 8, False).backward(g)
+        x.grad = None
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = SymQuantizer.apply(x, clip, 8, False)
+        y.backward(g)
+    for trial in range(2):
+        with torch.no_grad():
+            x.copy_(torch.randn(512, 4096, device="cuda") * (1.0 + trial))
+        graph.replay()
+        torch.cuda.synchronize()
+        yo, _, _ = O.sym_fwd(np_from(x), 512, 4096, 8, "bf16")
+        assert bits_equal(np_from(y), yo, "bf16")
+        assert bits_equal(np_from(x.grad), O.ste_bwd(np_from(g), np_from(x), -2.0, 2.0, "bf16"), "bf16")

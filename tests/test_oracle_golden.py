@@ -110,6 +110,16 @@ def test_bf16_reciprocal_multiply_equals_divide_exhaustively():
         a = (idx[None, :] / t2[chunk, None]).astype(np.float32)
         b = (idx[None, :] * rinv[chunk, None]).astype(np.float32)
         assert (rb(a) == rb(b)).all()
+    # wider quantizers (A16 / KV16): the bin index is rint() of a bf16 value, i.e. m * 2^j with m <= 255 -- the
+    # identity is scale invariant, checked here directly up to 2^15
+    big = np.unique(np.concatenate([np.arange(128, 256, dtype=np.float32) * np.float32(2.0 ** j) for j in range(1, 9)]))
+    big = np.concatenate([big, -big])
+    sel = t2[(t2 > 1e-6) & (t2 < 1e9)]
+    rsel = (np.float32(1.0) / sel).astype(np.float32)
+    for chunk in np.array_split(np.arange(sel.size), 16):
+        a = (big[None, :] / sel[chunk, None]).astype(np.float32)
+        b = (big[None, :] * rsel[chunk, None]).astype(np.float32)
+        assert (rb(a) == rb(b)).all()
 
 
 def test_w12_weight_branches_match_reference_fixtures():

@@ -245,6 +245,31 @@ def cpu_baseline(budget_s=15.0):
             "value_median": round(2 * ROWS * COLS / med / 1e9, 4)}
 
 
+def cpu_c_port(rows_sample=256):
+    """Second CPU line: the scalar C oracle (oracle/fq_oracle.c), one core, on a row sample of the same step."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    g = torch.Generator().manual_seed(1234)
+    w = (torch.randn(rows_sample, COLS, generator=g) * 0.02).bfloat16()
+    a = torch.randn(rows_sample, COLS, generator=g).bfloat16()
+    gw = (torch.randn(rows_sample, COLS, generator=g) * 1e-3).bfloat16()
+    tonp = lambda t: t.view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    wn, an, gn = tonp(w), tonp(a), tonp(gw)
+    O.lib()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.sym_fwd(wn, rows_sample, COLS, 4, "bf16", want_idx=False)
+        O.ste_bwd(gn, wn, -2.0, 2.0, "bf16")
+        O.sym_fwd(an, rows_sample, COLS, 8, "bf16", want_idx=False)
+        O.ste_bwd(gn, an, -2.0, 2.0, "bf16")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(2 * rows_sample * COLS / best / 1e9, 4), "unit": "Gelem/s", "cores": 1, "kind": "port",
+            "sample": f"{rows_sample} of 4096 rows of each tensor of the step, scalar C restatement (oracle/fq_oracle.c), best of 3"}
+
+
 def gpu_eager(wl, iters=5):
     """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd)."""
     import torch
@@ -360,6 +385,7 @@ def main():
             out["gpu_eager"] = gpu_eager(wl)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+                out["cpu_baseline_c_port"] = cpu_c_port()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,63 @@
+"""CPU tier, build container only (skipped where /root/reference is absent, e.g. on the GPU box):
+the REAL reference model code (models/modeling_llama_quant.py) is constructed on top of this package's
+drop-in by swapping `models.utils_quant` for `llm_qat_amd.utils_quant` -- the one-file switch of INTEGRATION.md.
+Construction, parameter names and the state_dict must be exactly the reference's; the forward must reach the
+HIP-backed quantizers (which refuse CPU tensors loudly -- there is no fallback to hide behind)."""
+import importlib
+import os
+import sys
+import warnings
+
+import pytest
+import torch
+
+REF = os.environ.get("LLMQAT_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference checkout not present")
+
+
+def _fresh_import(swap):
+    for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+        del sys.modules[name]
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    try:
+        if swap:
+            import llm_qat_amd.utils_quant as dropin
+            importlib.import_module("models")            # the package itself
+            sys.modules["models.utils_quant"] = dropin   # what INTEGRATION.md's re-export amounts to
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cfg_mod = importlib.import_module("models.configuration_llama")
+            mdl_mod = importlib.import_module("models.modeling_llama_quant")
+        return cfg_mod, mdl_mod
+    finally:
+        sys.path.remove(REF)
+
+
+def _build(cfg_mod, mdl_mod):
+    cfg = cfg_mod.LlamaConfig(vocab_size=128, hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4,
+                              max_position_embeddings=32, w_bits=4, a_bits=8, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    cfg.kv_bits = 4
+    cfg.use_cache = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return mdl_mod.LlamaForCausalLM(cfg)
+
+
+def test_reference_model_builds_on_the_dropin_with_identical_parameters():
+    ref_model = _build(*_fresh_import(swap=False))
+    ref_keys = [(k, tuple(v.shape)) for k, v in ref_model.state_dict().items()]
+    cfg_mod, mdl_mod = _fresh_import(swap=True)
+    import llm_qat_amd.utils_quant as dropin
+    assert mdl_mod.QuantizeLinear is dropin.QuantizeLinear and mdl_mod.SymQuantizer is dropin.SymQuantizer
+    model = _build(cfg_mod, mdl_mod)
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == ref_keys
+    lin = model.model.layers[0].self_attn.q_proj
+    assert isinstance(lin, dropin.QuantizeLinear) and (lin.w_bits, lin.a_bits) == (4, 8) and lin.act_quantizer is dropin.SymQuantizer
+    assert model.model.layers[0].self_attn.act_quantizer_k is dropin.SymQuantizer        # KV hooks (:253-254)
+    model.load_state_dict(ref_model.state_dict())                                         # checkpoints interchange
+    # the forward reaches the HIP-backed quantizer and fails loudly on CPU tensors: no silent eager fallback
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model(input_ids=torch.randint(2, 128, (1, 8)), use_cache=False)
+    for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+        del sys.modules[name]

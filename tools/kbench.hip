@@ -224,6 +224,20 @@ int main(int argc, char** argv) {
                hipLaunchKernelGGL((copy_xcd_kernel<1, true>), dim3((unsigned)(((nb + 7) / 8) * 8)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec);
            }, IT));
     COPY(1, true) COPY(2, true)
+    {   // does the relative placement of the read and the write stream matter? (same-bank / same-channel lock-step)
+        char* big;
+        CK(hipMalloc((void**)&big, 2 * bytes + (64u << 20)));
+        const size_t offs[] = {0, 256, 4096, 65536, 1u << 20, (1u << 20) + 4096 + 256, 8u << 20, (32u << 20) + 12345 * 16};
+        for (size_t off : offs) {
+            char name[96];
+            snprintf(name, sizeof name, "copy<UNR=1,NT=true> dst = src_end + %zu B", off);
+            uint4* dst = (uint4*)(big + bytes + off);
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)big, dst, nvec);
+                   }, IT));
+        }
+        CK(hipFree(big));
+    }
     uint32_t* sink;
     CK(hipMalloc(&sink, 64));
     report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {

@@ -270,6 +270,31 @@ def cpu_c_port(rows_sample=256):
             "sample": f"{rows_sample} of 4096 rows of each tensor of the step, scalar C restatement (oracle/fq_oracle.c), best of 3"}
 
 
+def parity_gate(wl, nrows=48):
+    """Reported with the timing: the kernels the step just ran, on a row sample of its own tensors, against
+    the CPU oracle -- bins and dequantized values and gradients must be bit-equal.  Part of the cpu_baseline leg (the only
+    place bench.py may touch oracle/), never inside a timed region."""
+    import numpy as np
+    import torch
+    import llm_qat_amd
+    from oracle import oracle as O
+    s = wl.sets[0]
+    idxs = torch.linspace(0, wl.rows - 1, nrows).long().to(s["w"].device)
+    tonp = lambda t: t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    res = {"rows_checked": int(nrows), "bins_bit_exact": True, "values_bit_exact": True, "grad_bit_exact": True}
+    for x, g, bits in ((s["w"], s["gw"], 4), (s["a"], s["ga"], 8)):
+        xs, gs = x[idxs].contiguous(), g[idxs].contiguous()
+        y, idx, _ = llm_qat_amd.ops.sym_quantize_debug(xs, bits, False)
+        yo, io, _ = O.sym_fwd(tonp(xs), nrows, wl.cols, bits, "bf16")
+        res["bins_bit_exact"] &= bool((idx.cpu().numpy() == io).all())
+        res["values_bit_exact"] &= bool((tonp(y) == yo).all())
+        tr = llm_qat_amd.ops.quantize_train("sym", xs, bits, False, -2.0, 2.0)
+        gx = llm_qat_amd.ops.ste_backward_mask(gs, -2.0, 2.0, tr[1], tr[2], nrows, wl.cols)
+        res["values_bit_exact"] &= bool((tonp(tr[0]) == yo).all())
+        res["grad_bit_exact"] &= bool((tonp(gx) == O.ste_bwd(tonp(gs), tonp(xs), -2.0, 2.0, "bf16")).all())
+    return res
+
+
 def gpu_eager(wl, iters=5):
     """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd)."""
     import torch
@@ -386,6 +411,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
                 out["cpu_baseline_c_port"] = cpu_c_port()
+                out["cpu_baseline"]["parity_gate"] = parity_gate(wl)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -194,3 +194,19 @@ def test_bf16_asym_reciprocal_multiplies_equal_divides():
     for bits in range(1, 9):
         S = np.float32(2 ** bits - 1)
         assert (rb(q / S) == rb(q * (np.float32(1.0) / S))).all()
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """GPU sanitizers are unavailable on the pool; the CPU oracle (what every kernel is judged against) is run over
+    ragged shapes and hostile values under AddressSanitizer + UBSan (oracle/selftest.c, `make -C oracle sanitize`)."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and ("cannot find -lasan" in r.stderr or "libasan" in r.stderr and "No such file" in r.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "oracle selftest ok" in r.stdout

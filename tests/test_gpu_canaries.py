@@ -1,0 +1,78 @@
+"""GPU tier: out-of-bounds WRITE check.  GPU AddressSanitizer is not available on the pool, so every output buffer of
+every entry point is embedded between canary regions (raw C-ABI calls on caller-owned pointers) and the canaries must
+survive, over ragged / misaligned / multi-chunk shapes and all kernel families (register, generic, two-pass, STE, mask, W1/W2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PAD = 4096  # bytes of canary on each side
+CANARY = 0xA5
+
+
+class Guarded:
+    """`nbytes` of device memory with PAD canary bytes before and after; `offset` shifts the payload start (alignment)."""
+
+    def __init__(self, nbytes, offset=0):
+        self.nbytes, self.offset = int(nbytes), int(offset)
+        self.buf = torch.full((PAD + self.offset + self.nbytes + PAD,), CANARY, dtype=torch.uint8, device="cuda")
+        self.ptr = self.buf.data_ptr() + PAD + self.offset
+
+    def payload(self):
+        return self.buf[PAD + self.offset: PAD + self.offset + self.nbytes]
+
+    def intact(self):
+        head = self.buf[: PAD + self.offset]
+        tail = self.buf[PAD + self.offset + self.nbytes:]
+        return bool((head == CANARY).all()) and bool((tail == CANARY).all())
+
+
+SHAPES = [(1, 1), (3, 7), (5, 33), (4, 264), (3, 4096), (2, 11008), (2, 16392), (1, 65536), (1, 70001), (7, 1000), (2, 40000), (65, 512)]
+
+
+@pytest.mark.parametrize("dtype,code,es", [(torch.bfloat16, 1, 2), (torch.float32, 0, 4), (torch.float16, 2, 2)])
+def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for rows, cols in SHAPES:
+        n = rows * cols
+        for off in (0, 2 if es == 2 else 4):          # aligned payloads and 2-/4-byte aligned ones
+            x = Guarded(n * es, off)
+            x.payload().view(dtype).copy_((torch.randn(n, generator=g, device="cuda") * 1.5).to(dtype))
+            gr = Guarded(n * es, off)
+            gr.payload().view(dtype).copy_(torch.randn(n, generator=g, device="cuda").to(dtype))
+            y, gx = Guarded(n * es, off), Guarded(n * es, off)
+            idx, scale, bounds = Guarded(n * 4), Guarded(rows * 8), Guarded(rows * 8)
+            wsb = L.fq_rowwise_workspace_bytes(rows, cols, code)
+            ws = Guarded(max(wsb, 8))
+            mb = L.fq_ste_mask_bytes(rows, cols, code)
+            mask = Guarded(max(mb, 8))
+            everything = [x, gr, y, gx, idx, scale, bounds, ws, mask]
+            tag = f"{dtype} [{rows},{cols}] off={off}"
+
+            def ok(rc, what, allow=()):
+                assert rc == 0 or rc in allow, f"{tag} {what}: rc={rc} {L.fq_last_error()}"
+                torch.cuda.synchronize()
+                for b in everything:
+                    assert b.intact(), f"{tag} {what}: canary overwritten"
+
+            for bits in (4, 8):
+                ok(L.fq_sym_fwd(x.ptr, y.ptr, rows, cols, bits, code, 0, bounds.ptr, ws.ptr, wsb, st), "sym_fwd")
+                ok(L.fq_asym_fwd(x.ptr, y.ptr, rows, cols, bits, code, 0, bounds.ptr, ws.ptr, wsb, st), "asym_fwd")
+                ok(L.fq_sym_fwd_debug(x.ptr, y.ptr, idx.ptr, scale.ptr, rows, cols, bits, code, 0, ws.ptr, wsb, st), "sym_fwd_debug")
+                ok(L.fq_asym_fwd_debug(x.ptr, y.ptr, idx.ptr, scale.ptr, rows, cols, bits, code, 1, ws.ptr, wsb, st), "asym_fwd_debug")
+            ok(L.fq_ste_bwd(gr.ptr, x.ptr, gx.ptr, n, -2.0, 2.0, code, st), "ste_bwd")
+            ok(L.fq_ste_bwd_rows(gr.ptr, x.ptr, gx.ptr, rows, cols, -2.0, 2.0, bounds.ptr, code, st), "ste_bwd_rows")
+            if mb:
+                ok(L.fq_sym_fwd_train(x.ptr, y.ptr, rows, cols, 8, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr, mb, st), "sym_fwd_train", allow=(-8,))
+                if off == 0:
+                    ok(L.fq_ste_bwd_mask(gr.ptr, gx.ptr, rows, cols, -2.0, 2.0, bounds.ptr, mask.ptr, mb, code, st), "ste_bwd_mask")
+                ok(L.fq_asym_fwd_train(x.ptr, y.ptr, rows, cols, 4, code, 0, -0.5, 0.75, bounds.ptr, mask.ptr, mb, st), "asym_fwd_train", allow=(-8,))
+            sc = Guarded(rows * es)
+            sc.payload().view(dtype).fill_(0.05)
+            everything.append(sc)
+            for wb in (1, 2):
+                ok(L.fq_w12_fwd(x.ptr, sc.ptr, y.ptr, rows, cols, wb, 1, code, st), "w12_fwd")

@@ -412,6 +412,14 @@ def test_randomized_stress_all_paths(ops):
             xt = torch.from_numpy(x).to(TD[dtype])
             x_np, xd = np_from(xt), xt.cuda()
             g_np, gd = make_input(rng, (rows, cols), dtype, "act")
+            layout = rng.random()
+            if layout < 0.15:      # contiguous but only element-aligned storage (views into a flat buffer, as FSDP hands out)
+                flat = torch.empty(rows * cols + 1, dtype=TD[dtype], device="cuda")
+                flat[1:].copy_(xd.reshape(-1))
+                xd = flat[1:].view(rows, cols)
+            elif layout < 0.3:     # non-contiguous (transposed storage)
+                xd = xd.t().contiguous().t()
+                gd = gd.t().contiguous().t()
             r, c = O.rows_cols((rows, cols), layerwise)
             if kind == "sym":
                 yo, io, _ = O.sym_fwd(x_np, r, c, bits, dtype)

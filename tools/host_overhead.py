@@ -14,9 +14,21 @@ x = torch.randn(64, 256, device="cuda", dtype=torch.bfloat16)
 xg = x.clone().requires_grad_(True)
 g = torch.ones_like(x)
 N = 2000
+from llm_qat_amd import ops
+res = ops.train_forward("sym", x, 8, False, -2.0, 2.0)
+_, side, rows, cols = res
+outs = [SymQuantizer.apply(xg, clip, 8, False) for _ in range(64)]
+
+
+def many_backward():
+    torch.autograd.backward(outs, [g] * 64, retain_graph=True)
+
 for name, fn in (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, clip, 8, False)),
                  ("llm_qat_amd fwd (grad)", lambda: SymQuantizer.apply(xg, clip, 8, False)),
                  ("llm_qat_amd fwd+bwd", lambda: SymQuantizer.apply(xg, clip, 8, False).backward(g)),
+                 ("ops.train_forward only", lambda: ops.train_forward("sym", x, 8, False, -2.0, 2.0)),
+                 ("ops.train_backward only", lambda: ops.train_backward(g, side, rows, cols, -2.0, 2.0)),
+                 ("autograd.backward over 64 nodes (/64)", many_backward),
                  ("eager chain fwd (grad)", lambda: EagerSym.apply(xg, clip, 8, False)),
                  ("eager chain fwd+bwd", lambda: EagerSym.apply(xg, clip, 8, False).backward(g))):
     for _ in range(50):
@@ -27,4 +39,5 @@ for name, fn in (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, cli
         fn()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
-    print(f"{name:28s} {1e6 * (t1 - t0) / N:7.1f} us/call (host)")
+    per = 1e6 * (t1 - t0) / N / (64 if "64 nodes" in name else 1)
+    print(f"{name:40s} {per:7.1f} us/call (host)")

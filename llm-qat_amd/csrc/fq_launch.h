@@ -21,11 +21,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Cache policy of the 16-byte streams, from tools/kbench on MI355X (every tensor is touched once per launch):
 //  * stores: non-temporal from 4 MiB up (a tensor that size cannot stay in an XCD's 4 MiB L2 anyway).  NT stores
 //    win at every size measured: 16 MB forward 7.3 -> 5.9 us, 45 MB 17.9 -> 14.2 us, 90 MB 34.3 -> 31.9 us.
-//  * loads: non-temporal only from 64 MiB up.  Below that the input was typically produced by the kernel just
+//  * loads: non-temporal only from 72 MiB up.  Below that the input was typically produced by the kernel just
 //    before and still sits in the 256 MiB Infinity Cache, where plain loads are faster (16 MB: 5.9 vs 6.1 us,
-//    45 MB: 14.2 vs 16.1 us); the big MLP weights come from HBM, where NT loads are faster (90 MB: 31.1 vs 31.9 us).
+//    45 MB: 14.2 vs 16.1 us, 67 MB: 20.4 vs 22.2 us); the big MLP weights come from HBM, where NT loads are faster
+//    (84 MB: 27.8 vs 28.8 us, 90 MB: 30.3 vs 31.3 us, 113 MB: 37.0 vs 38.0 us).
 constexpr int64_t NT_STORE_MIN_BYTES = 4ll << 20;
-constexpr int64_t NT_LOAD_MIN_BYTES = 64ll << 20;
+constexpr int64_t NT_LOAD_MIN_BYTES = 72ll << 20;
 
 constexpr int64_t REG_MAX_VEC = 1024 * 8;    // longest row (in 16-byte vectors) the register kernels hold
 constexpr int64_t GENERIC_MAX_COLS = 32768;  // longest row the scalar-load kernel sweeps

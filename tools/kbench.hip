@@ -180,6 +180,16 @@ static void launch_sym(const void* x, void* y, float* bounds, int64_t rows, int6
     hipLaunchKernelGGL((row_reg_kernel<BF16, TPR, VPT, false, FAST, NTL, NTS>), dim3((unsigned)grid), dim3(TPR == 64 ? 256 : TPR), 0, 0, a);
 }
 
+template <int TPR, bool NTL, bool NTS>
+static bool launch_sym_any(int vpt, const void* x, void* y, float* bounds, int64_t rows, int64_t cols) {
+    switch (vpt) {
+#define V(N) case N: launch_sym<TPR, N, true, NTL, NTS>(x, y, bounds, rows, cols, 4); return true;
+        V(1) V(2) V(3) V(4) V(5) V(6) V(7) V(8)
+#undef V
+        default: return false;
+    }
+}
+
 int main(int argc, char** argv) {
     const int64_t rows = argc > 2 ? atoll(argv[1]) : 4096, cols = argc > 2 ? atoll(argv[2]) : 11008;
     const int64_t n = rows * cols;
@@ -260,6 +270,23 @@ int main(int argc, char** argv) {
     SYM(512, 3, true, false, false) SYM(512, 3, true, true, true) SYM(1024, 2, true, true, true) SYM(256, 6, false, true, true)
     SYM(256, 2, true, false, false) SYM(256, 2, true, true, true) SYM(256, 2, true, true, false) SYM(256, 2, true, false, true) SYM(128, 4, true, true, true) SYM(64, 8, true, true, true) SYM(512, 1, true, true, true)
     SYM(256, 7, true, true, true) SYM(512, 4, true, true, true)
+
+    // ---- full launch-shape sweep: every TPR whose VPT = ceil(nvec/TPR) fits in 1..8
+    if (argc > 3) {
+#define SWEEP(TPR)                                                                                                         \
+    {                                                                                                                      \
+        const int vpt = (int)((nv_row + TPR - 1) / TPR);                                                                   \
+        if (vpt >= 1 && vpt <= 8) {                                                                                        \
+            char nm[96];                                                                                                   \
+            snprintf(nm, sizeof nm, "sweep sym_fwd TPR=%d VPT=%d NT/NT", TPR, vpt);                                        \
+            report(nm, 2.0 * bytes, time_it([&](int i) { launch_sym_any<TPR, true, true>(vpt, b.x[i % NS], b.y[i % NS], b.bounds[i % NS], rows, cols); }, IT)); \
+            snprintf(nm, sizeof nm, "sweep sym_fwd TPR=%d VPT=%d plain/NT", TPR, vpt);                                     \
+            report(nm, 2.0 * bytes, time_it([&](int i) { launch_sym_any<TPR, false, true>(vpt, b.x[i % NS], b.y[i % NS], b.bounds[i % NS], rows, cols); }, IT)); \
+        }                                                                                                                  \
+    }
+        SWEEP(64) SWEEP(128) SWEEP(256) SWEEP(512) SWEEP(1024)
+        return 0;
+    }
 
     // ---- STE backward variants
 #define STE(U, NT)  STE2(U, NT, NT)

@@ -111,7 +111,7 @@ class Workload:
     def fwd(self, s, leg):
         x, y, b, m, bits = (s["w"], s["yw"], s["bw"], s["mw"], 4) if leg == "w" else (s["a"], s["ya"], s["ba"], s["ma"], 8)
         rc = self.L.fq_sym_fwd_train(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16,
-                                     self._lib.SEM_CPU_EAGER, -2.0, 2.0, b.data_ptr(), m.data_ptr(), self.mask_bytes, None, self.stream)
+                                     self._lib.SEM_CPU_EAGER, -2.0, 2.0, b.data_ptr(), m.data_ptr(), self.mask_bytes, self.stream)
         if rc:
             self._lib.check(rc, "fq_sym_fwd_train")
 

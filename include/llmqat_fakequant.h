@@ -130,19 +130,14 @@ int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
  *                    use fq_*_fwd + fq_ste_bwd[_rows] then.  Contents need no initialisation.
  * fq_*_fwd_train     lo/hi = the STE clip (clip_val[0], clip_val[1]); row_bounds_out and mask_out required.
  *                    Returns FQ_ERR_UNSUPPORTED if x/y are not 16-byte aligned.
- *                    clipped_flag (optional, may be NULL): an int32 the caller zeroed; the kernel stores 1 into it if
- *                    ANY row of the tensor can be clipped.  It may live in pinned HOST memory: once the launch is
- *                    known to have completed (event query -- no synchronisation), a 0 tells the caller that the STE
- *                    backward of this tensor is the identity, so it can hand grad_output through without a kernel
- *                    (weights, whose values stay far inside the clip, are always that case).
  * fq_ste_bwd_mask    SymQuantizer.backward / AsymQuantizer.backward (utils_quant.py:77-87, :152-162) from
  *                    (row_bounds, mask) of the matching forward; lo/hi must be the same values.
  */
 size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype);
 int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
-                     float* row_bounds_out, void* mask_out, size_t mask_bytes, int32_t* clipped_flag, void* stream);
+                     float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
 int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
-                      float* row_bounds_out, void* mask_out, size_t mask_bytes, int32_t* clipped_flag, void* stream);
+                      float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
 int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,
                     const void* mask, size_t mask_bytes, int dtype, void* stream);
 

@@ -57,7 +57,7 @@ def _bind(L):
     L.fq_ste_mask_bytes.restype = sz
     for name in ("fq_sym_fwd_train", "fq_asym_fwd_train"):
         f = getattr(L, name)
-        f.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp, vp]
+        f.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp]
         f.restype = i32
     L.fq_ste_bwd_mask.argtypes = [vp, vp, i64, i64, f32, f32, vp, vp, sz, i32, vp]
     L.fq_ste_bwd_mask.restype = i32

@@ -82,7 +82,6 @@ struct MaskArgs {
     void* mask = nullptr;
     size_t bytes = 0;
     float lo = 0.f, hi = 0.f;
-    int32_t* clipped_flag = nullptr;
 };
 
 template <bool ASYM>
@@ -96,7 +95,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, sem);
-    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, nullptr};
+    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f};
     if (mk) {
         if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
         const int64_t mrw = mask_row_words(cols, esize_of(dtype));
@@ -106,7 +105,6 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
         a.mask_row_words = mrw;
         a.lo = host_rb(mk->lo, dtype);
         a.hi = host_rb(mk->hi, dtype);
-        a.clipped_flag = mk->clipped_flag;
     }
     hipStream_t st = (hipStream_t)stream;
     // reciprocal-multiply instead of IEEE divide (only honoured for bf16).  Sym: valid for every bit width, because
@@ -166,15 +164,15 @@ FQ_API size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype) {
 }
 
 FQ_API int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
-                            float* row_bounds_out, void* mask_out, size_t mask_bytes, int32_t* clipped_flag, void* stream) {
+                            float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
     MaskArgs mk;
-    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi; mk.clipped_flag = clipped_flag;
+    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi;
     return rowwise<false>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
 }
 FQ_API int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
-                             float* row_bounds_out, void* mask_out, size_t mask_bytes, int32_t* clipped_flag, void* stream) {
+                             float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
     MaskArgs mk;
-    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi; mk.clipped_flag = clipped_flag;
+    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi;
     return rowwise<true>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
 }
 

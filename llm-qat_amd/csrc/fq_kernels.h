@@ -33,10 +33,6 @@ struct RowArgs {
     uint64_t* mask;
     int64_t mask_row_words;
     float lo, hi;
-    // optional (training mode): a word that is set to 1 if ANY row of the tensor can be clipped.  May live in
-    // pinned host memory: the caller reads it later, without synchronising, to learn that the STE backward is the
-    // identity for the whole tensor.
-    int32_t* clipped_flag;
 };
 
 // STE bit mask layout (private to the forward/backward kernel pair, independent of launch shape):
@@ -170,8 +166,6 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 
     // Elementwise pass.  Rows that can actually be clipped also emit the STE bit mask for the backward.
     const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
-    if (want_mask && a.clipped_flag && t == 0)
-        __hip_atomic_store(a.clipped_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // idempotent; visible at kernel end
     const bool sym_clip = a.lo == -a.hi;
     uint64_t* mrow = a.mask + row * a.mask_row_words;
     int32_t* idxr = (DBG && a.idx) ? a.idx + row * a.cols : nullptr;

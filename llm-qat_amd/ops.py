@@ -129,9 +129,8 @@ def _mask_bytes(rows, cols, code):
     return v
 
 
-def train_forward(kind, x, num_bits, layerwise, lo, hi, flag_ptr=None):
-    """-> (y, side, rows, cols) or None.  `side` is one uint8 buffer: float[rows][2] bounds followed by the mask.
-    flag_ptr: optional address of a zeroed int32 (pinned host memory) that the kernel sets if any row can be clipped."""
+def train_forward(kind, x, num_bits, layerwise, lo, hi):
+    """-> (y, side, rows, cols) or None.  `side` is one uint8 buffer: float[rows][2] bounds followed by the mask."""
     if x.device.type != "cuda":
         _prep(x, f"{kind}_quantize")
     code = _DTYPES.get(x.dtype)
@@ -152,10 +151,10 @@ def train_forward(kind, x, num_bits, layerwise, lo, hi, flag_ptr=None):
     if dev is not None and dev != torch.cuda.current_device():
         with torch.cuda.device(dev):
             rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
-                    flag_ptr, torch.cuda.current_stream(dev).cuda_stream)
+                    torch.cuda.current_stream(dev).cuda_stream)
     else:
         rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
-                flag_ptr, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.current_stream().cuda_stream)
     if rc:
         if rc == _lib.ERR_UNSUPPORTED:
             return None
@@ -201,7 +200,7 @@ def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
     with _DeviceOf(x):
         rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, float(lo), float(hi),
-                bounds.data_ptr(), mask.data_ptr(), mbytes, None, _stream(x))
+                bounds.data_ptr(), mask.data_ptr(), mbytes, _stream(x))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, f"{kind}_quantize_train")

@@ -32,53 +32,6 @@ if os.environ.get("LLMQAT_AMD_ROW_BOUNDS", "1") == "0":
     _BACKWARD_MODE = "plain"
 
 
-# Opt-in: when the forward found that NO row of the tensor can be clipped (weights: always), the STE backward is
-# the identity -- hand grad_output through instead of launching a copy kernel.  The forward kernel reports that
-# through one int32 in pinned host memory; the backward trusts it only if an event recorded right after the launch
-# has completed (query, never a synchronisation) -- otherwise it launches the ordinary kernel.  Same values either way.
-_ALIAS_IDENTITY = os.environ.get("LLMQAT_AMD_ALIAS_IDENTITY_GRAD", "0") == "1"
-
-
-def alias_identity_grad(flag=True):
-    global _ALIAS_IDENTITY
-    _ALIAS_IDENTITY = bool(flag)
-
-
-class _FlagRing:
-    """int32 flags in pinned host memory, handed out round-robin; a generation number per slot tells a late reader
-    that its slot has been recycled (then it simply does not take the shortcut)."""
-
-    def __init__(self, n=8192):
-        self.flags = torch.zeros(n, dtype=torch.int32).pin_memory()
-        self.host = self.flags.numpy()
-        self.base = self.flags.data_ptr()
-        self.gen = [0] * n
-        self.n, self.next = n, 0
-        self.lock = threading.Lock()
-
-    def acquire(self):
-        with self.lock:
-            i = self.next
-            self.next = (i + 1) % self.n
-            self.gen[i] += 1
-            g = self.gen[i]
-        self.host[i] = 0
-        return i, g, self.base + 4 * i
-
-    def is_clear(self, i, g):
-        return self.gen[i] == g and int(self.host[i]) == 0
-
-
-_ring = None
-
-
-def _flag_ring():
-    global _ring
-    if _ring is None:
-        _ring = _FlagRing()
-    return _ring
-
-
 def set_backward_mode(mode):
     global _BACKWARD_MODE
     if mode not in ("mask", "bounds", "plain"):
@@ -107,16 +60,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         ctx.row_bounds = None
         if mode == "mask":
             lo, hi = _clip_pair(clip_val)
-            ctx.alias = None
-            if _ALIAS_IDENTITY and input.is_cuda and not torch.cuda.is_current_stream_capturing():
-                slot, gen, flag_ptr = _flag_ring().acquire()
-                res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi, flag_ptr=flag_ptr)
-                if res is not None:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    ctx.alias = (slot, gen, ev)
-            else:
-                res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
+            res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
             if res is not None:
                 out, ctx.side, rows, cols = res
                 ctx.fq_mode, ctx.clip, ctx.rows_cols = "mask", (lo, hi), (rows, cols)
@@ -136,11 +80,6 @@ class _FakeQuantFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
         if ctx.fq_mode == "mask":
-            al = ctx.alias
-            if al is not None and not torch.cuda.is_current_stream_capturing():
-                slot, gen, ev = al
-                if ev.query() and _ring.is_clear(slot, gen):
-                    return grad_output, None, None, None  # no row can be clipped: the STE is the identity here
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
             return ops.train_backward(grad_output, ctx.side, rows, cols, lo, hi), None, None, None

@@ -68,7 +68,7 @@ def test_argument_validation_without_gpu():
     assert L.fq_ste_mask_bytes(2048, 4096, 1) == 2048 * 4096 // 8
     assert L.fq_ste_mask_bytes(4, 100, 1) == 0 and L.fq_ste_mask_bytes(4, 100, 0) == 4 * 1 * 4 * 8
     assert L.fq_ste_mask_bytes(1, 4096 * 11008, 1) == 0
-    assert L.fq_sym_fwd_train(p, p + 16, 1, 8, 4, 1, 0, -2.0, 2.0, None, None, 0, None, None) == -4
+    assert L.fq_sym_fwd_train(p, p + 16, 1, 8, 4, 1, 0, -2.0, 2.0, None, None, 0, None) == -4
     assert L.fq_ste_bwd_mask(p, p + 16, 1, 100, -2.0, 2.0, p, p, 64, 1, None) == -8
 
 

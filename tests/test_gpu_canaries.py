@@ -50,8 +50,7 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
             ws = Guarded(max(wsb, 8))
             mb = L.fq_ste_mask_bytes(rows, cols, code)
             mask = Guarded(max(mb, 8))
-            flag = Guarded(4)
-            everything = [x, gr, y, gx, idx, scale, bounds, ws, mask, flag]
+            everything = [x, gr, y, gx, idx, scale, bounds, ws, mask]
             tag = f"{dtype} [{rows},{cols}] off={off}"
 
             def ok(rc, what, allow=()):
@@ -68,10 +67,10 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
             ok(L.fq_ste_bwd(gr.ptr, x.ptr, gx.ptr, n, -2.0, 2.0, code, st), "ste_bwd")
             ok(L.fq_ste_bwd_rows(gr.ptr, x.ptr, gx.ptr, rows, cols, -2.0, 2.0, bounds.ptr, code, st), "ste_bwd_rows")
             if mb:
-                ok(L.fq_sym_fwd_train(x.ptr, y.ptr, rows, cols, 8, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr, mb, flag.ptr, st), "sym_fwd_train", allow=(-8,))
+                ok(L.fq_sym_fwd_train(x.ptr, y.ptr, rows, cols, 8, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr, mb, st), "sym_fwd_train", allow=(-8,))
                 if off == 0:
                     ok(L.fq_ste_bwd_mask(gr.ptr, gx.ptr, rows, cols, -2.0, 2.0, bounds.ptr, mask.ptr, mb, code, st), "ste_bwd_mask")
-                ok(L.fq_asym_fwd_train(x.ptr, y.ptr, rows, cols, 4, code, 0, -0.5, 0.75, bounds.ptr, mask.ptr, mb, flag.ptr, st), "asym_fwd_train", allow=(-8,))
+                ok(L.fq_asym_fwd_train(x.ptr, y.ptr, rows, cols, 4, code, 0, -0.5, 0.75, bounds.ptr, mask.ptr, mb, st), "asym_fwd_train", allow=(-8,))
             sc = Guarded(rows * es)
             sc.payload().view(dtype).fill_(0.05)
             everything.append(sc)

@@ -70,19 +70,15 @@ def main():
     rows = []
     for wb, ab, kvb in ((4, 8, 4), (8, 8, 8)):
         for ckpt in (False, True):
-            for label, quant, wcache, alias in (("no quantization (bf16 linears)", NoQuant, False, False),
-                                                ("reference eager chain", TL.EagerQuant(), False, False),
-                                                ("llm_qat_amd", UQ, False, False), ("llm_qat_amd + weight cache", UQ, True, False),
-                                                ("llm_qat_amd + weight cache + identity-grad alias", UQ, True, True)):
+            for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
+                                         ("llm_qat_amd", UQ, False), ("llm_qat_amd + weight cache", UQ, True)):
                 if quant is NoQuant:
                     model = build(quant, args.layers, 32, 32, 32)
                 else:
                     model = build(quant, args.layers, wb, ab, kvb)
                 llm_qat_amd.enable_weight_quant_cache(wcache)
-                llm_qat_amd.alias_identity_grad(alias)
                 ms = timed(lambda: step(model, ids, ckpt), args.iters)
                 llm_qat_amd.enable_weight_quant_cache(False)
-                llm_qat_amd.alias_identity_grad(False)
                 rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, impl=label, ms_per_step=round(ms, 2), layers=args.layers))
                 print(rows[-1], flush=True)
                 del model

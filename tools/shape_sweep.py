@@ -61,7 +61,7 @@ def main():
             for kind in ("sym", "asym"):
                 fwd = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
                 us_f = t(lambda s: chk(fwd(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, bits, code, 0, -2.0, 2.0, s["b"].data_ptr(),
-                                           s["m"].data_ptr(), s["mb"], None, st)))
+                                           s["m"].data_ptr(), s["mb"], st)))
                 us_b = t(lambda s: chk(L.fq_ste_bwd_mask(s["g"].data_ptr(), s["gx"].data_ptr(), rows, cols, -2.0, 2.0, s["b"].data_ptr(),
                                                          s["m"].data_ptr(), s["mb"], code, st)))
                 us_bx = t(lambda s: chk(L.fq_ste_bwd(s["g"].data_ptr(), s["x"].data_ptr(), s["gx"].data_ptr(), n, -2.0, 2.0, code, st)))

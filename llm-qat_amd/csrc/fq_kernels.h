@@ -52,19 +52,20 @@ __device__ __forceinline__ void ste_mask_store(const float (&f)[N], float lo, fl
     }
     if (lane < N) gw[lane] = mine;
 }
-// apply group mask words (wave-uniform, in SGPRs) to this lane's gradient vector
-template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g, const uint64_t* mw, int lane) {
+// apply group mask words (wave-uniform, in SGPRs) to this lane's gradient vector.  inverse_ballot turns a 64-bit
+// wave mask straight into a per-lane predicate, so each half-dword costs one v_cndmask with the SGPR pair as the
+// selector (and gfx950's v_bitop3 folds the two ANDs): 3 VALU ops per dword instead of a shift/and/compare chain.
+template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g, const uint64_t* mw) {
     using T = Ty<DT>;
     uint32_t w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         if constexpr (T::EPD == 1) {
-            if ((mw[d] >> lane) & 1ull) w[d] = 0u;
+            w[d] = __builtin_amdgcn_inverse_ballot_w64(mw[d]) ? 0u : w[d];
         } else {
-            uint32_t keep = 0xFFFFFFFFu;
-            if ((mw[2 * d] >> lane) & 1ull) keep &= 0xFFFF0000u;
-            if ((mw[2 * d + 1] >> lane) & 1ull) keep &= 0x0000FFFFu;
-            w[d] &= keep;
+            const uint32_t k0 = __builtin_amdgcn_inverse_ballot_w64(mw[2 * d]) ? 0xFFFF0000u : 0xFFFFFFFFu;
+            const uint32_t k1 = __builtin_amdgcn_inverse_ballot_w64(mw[2 * d + 1]) ? 0x0000FFFFu : 0xFFFFFFFFu;
+            w[d] &= k0 & k1;
         }
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
             uint64_t mw[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) mw[e] = mrow[grp * EPV + e];  // wave-uniform address -> scalar loads
-            const uint4 o = ste_mask_apply<DT>(rg[i], mw, (int)((vs + v) & 63));
+            const uint4 o = ste_mask_apply<DT>(rg[i], mw);
             if (v < nvec) st16<NTS>(&or_[v], o);
         }
     }

@@ -304,3 +304,25 @@ def test_python_level_graph_capture(pkg):
         yo, _, _ = O.sym_fwd(np_from(x), 512, 4096, 8, "bf16")
         assert bits_equal(np_from(y), yo, "bf16")
         assert bits_equal(np_from(x.grad), O.ste_bwd(np_from(g), np_from(x), -2.0, 2.0, "bf16"), "bf16")
+
+
+def test_plain_c_host_links_and_matches_oracle(tmp_path):
+    """the boundary is a real C ABI: a C program (no Python, no torch) built with gcc against include/*.h and the .so
+    drives both data flows on the GPU and matches the oracle bit for bit"""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    exe = str(tmp_path / "abi_smoke")
+    cmd = ["gcc", "-std=c11", "-O2", "-fno-fast-math", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(rocm, "include"), os.path.join(ROOT, "tests", "c_host", "abi_smoke.c"), os.path.join(ROOT, "oracle", "fq_oracle.c"),
+           "-L", os.path.join(ROOT, "llm-qat_amd"), "-lllmqat_fakequant", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{os.path.join(ROOT, 'llm-qat_amd')}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "c host ok" in r.stdout

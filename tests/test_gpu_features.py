@@ -326,3 +326,18 @@ def test_plain_c_host_links_and_matches_oracle(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "c host ok" in r.stdout
+
+
+def test_mask_mode_backward_needs_no_input_storage(pkg):
+    """FSDP full_shard frees the unsharded flat parameter between forward and backward.  In the default (mask) mode the
+    backward never touches the forward's input, so it works even after that storage is gone."""
+    from llm_qat_amd.utils_quant import SymQuantizer
+    assert pkg.get_backward_mode() == "mask"
+    flat = (torch.randn(2 * 512 * 1024, device="cuda") * 1.2).bfloat16()
+    w = flat[512 * 1024:].view(512, 1024).requires_grad_(True)          # a view into a flat buffer, as FSDP hands out
+    g = torch.randn(512, 1024, device="cuda").bfloat16()
+    ref_mask = ((w.detach() >= 2) | (w.detach() <= -2)).clone()
+    y = SymQuantizer.apply(w, torch.tensor([-2.0, 2.0]), 4, False)
+    flat.untyped_storage().resize_(0)                                   # "reshard": the weight's memory is released
+    (gw,) = torch.autograd.grad(y, w, g)
+    assert torch.equal(gw, torch.where(ref_mask, torch.zeros_like(g), g))

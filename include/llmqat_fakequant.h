@@ -142,6 +142,24 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
                     const void* mask, size_t mask_bytes, int dtype, void* stream);
 
 /*
+ * SymQuantizer.forward as it executes under CUDA autocast -- torch.autocast("cuda", dtype=bf16|fp16), which is how
+ * LLM-QAT trains (`--bf16 True`, utils/kd_trainer.py:106).  `reciprocal` is on autocast's fp32 list, so for a 16-bit
+ * input  s = (2^(b-1)-1) / (max + 1e-6)  (models/utils_quant.py:71) comes back in fp32 and every later op of :72 is
+ * promoted:  t1 = round_to_dtype(max + 1e-6);  s = (1/t1)*qmax;  y = round(x*s) / (s + 1e-6)  in fp32; the reference
+ * returns an fp32 tensor.  (fp32 inputs are unaffected by autocast: use fq_sym_fwd.  AsymQuantizer and the 1-/2-bit
+ * branches contain no autocast-listed op: use fq_asym_fwd / fq_w12_fwd.)
+ *   dtype     FQ_DTYPE_BF16 or FQ_DTYPE_F16 (the input)
+ *   wide_out  1: y is fp32 [rows, cols], exactly what the reference returns (KV hooks, direct callers)
+ *             0: y has the input dtype = that fp32 result rounded once to it -- bit-identical to what F.linear's own
+ *                autocast cast makes of it next, so QuantizeLinear can skip the fp32 round trip (2 instead of 4+4+2 B/elem)
+ *   row_bounds_out / mask_out  optional training-mode outputs, as in fq_sym_fwd_train (mask_out needs row_bounds_out);
+ *             the backward is fq_ste_bwd_mask / fq_ste_bwd on the input dtype (cast an fp32 grad_output first).
+ * Returns FQ_ERR_UNSUPPORTED for rows longer than 32768 elements (or, with a mask, shapes fq_ste_mask_bytes rejects).
+ */
+int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
+                        float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+
+/*
  * QuantizeLinear's 1- and 2-bit weight branches -- models/utils_quant.py:202-242, elementwise part:
  *   w_bits==1 : q = sc * sign(w / sc)
  *   w_bits==2 : q = sc * (round(clamp(w / sc, -0.99, 0.99) * 2 - 0.5) + 0.5) / 2

@@ -19,7 +19,7 @@ EXPORTS = (
     "fq_sym_fwd", "fq_asym_fwd", "fq_sym_fwd_debug", "fq_asym_fwd_debug",
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
-    "fq_w12_fwd",
+    "fq_w12_fwd", "fq_sym_fwd_autocast",
 )
 ERR_UNSUPPORTED = -8
 
@@ -63,6 +63,8 @@ def _bind(L):
     L.fq_ste_bwd_mask.restype = i32
     L.fq_w12_fwd.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
     L.fq_w12_fwd.restype = i32
+    L.fq_sym_fwd_autocast.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp]
+    L.fq_sym_fwd_autocast.restype = i32
     return L
 
 

@@ -176,6 +176,31 @@ FQ_API int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols,
     return rowwise<true>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
 }
 
+FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
+                               float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
+    if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16)
+        return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors (fp32 tensors are unaffected by autocast)");
+    if (bits < 2 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [2, 31]", bits);
+    if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
+    if (rows == 0 || cols == 0) return ok();
+    if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
+    if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
+    const Consts c = make_consts(bits, dtype, FQ_SEM_DEVICE_EAGER);
+    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f};
+    if (mask_out) {
+        if (!row_bounds_out) return fail(FQ_ERR_NULL, "a mask needs row_bounds_out too");
+        const int64_t mrw = mask_row_words(cols, 2);
+        if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
+        if (mask_bytes < (size_t)rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small: need %zu bytes", (size_t)rows * mrw * 8);
+        a.mask = (uint64_t*)mask_out;
+        a.mask_row_words = mrw;
+        a.lo = host_rb(lo, dtype);
+        a.hi = host_rb(hi, dtype);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide_out != 0, a, st) : launch_sym_autocast<F16>(wide_out != 0, a, st);
+}
+
 FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,
                            const void* mask, size_t mask_bytes, int dtype, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);

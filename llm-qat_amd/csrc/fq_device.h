@@ -203,6 +203,30 @@ template <int DT> __device__ __forceinline__ SymRow sym_row(float m, SymConst k)
     return r;
 }
 
+// ---- SymQuantizer as it executes under CUDA autocast (torch.autocast("cuda", bf16|fp16), LLM-QAT's --bf16 run) ----
+// `reciprocal` is on autocast's fp32 list, so  s = qmax / (max + 1e-6)  comes back as an fp32 tensor and every op
+// after it is promoted to fp32:  t1 = rb(max + 1e-6)  (the add still runs in the tensor dtype; the GPU keeps the
+// scalar in fp32),  s = (1/t1) * qmax,  idx = round(x * s),  y = idx / (s + 1e-6)  -- all fp32, output fp32.
+// (measured on MI355X: tools/autocast_probe.py).  AC: 0 = no autocast, 1 = autocast, result rounded once to the
+// tensor dtype (what F.linear's autocast cast does to it next), 2 = autocast, fp32 result as the reference returns it.
+template <int DT> __device__ __forceinline__ SymRow sym_row_autocast(float m, float qmax) {
+    SymRow r;
+    const float t1 = Ty<DT>::rb(m + 1e-6f);
+    r.s = (1.0f / t1) * qmax;
+    r.t2 = r.s + 1e-6f;
+    r.rinv = 1.0f / r.t2;
+    return r;
+}
+// idx / t2 without the IEEE-divide sequence: Markstein's correction of a reciprocal multiply is the correctly
+// rounded quotient (r.rinv is the correctly rounded 1/t2); `e == 0` keeps the sign of a zero numerator.
+// Checked against the division on 9e7 quotients in tests/c_host/markstein_check.c.
+__device__ __forceinline__ float div_by_row(float a, const SymRow& r) {
+    const float q0 = a * r.rinv;
+    const float e = __builtin_fmaf(-q0, r.t2, a);
+    return e == 0.0f ? q0 : __builtin_fmaf(e, r.rinv, q0);
+}
+__device__ __forceinline__ float sym_elem_autocast(float x, const SymRow& r) { return div_by_row(__builtin_rintf(x * r.s), r); }
+
 struct AsymConst {
     float S;      // 2^bits - 1 as fp32
     float invS;   // fp32 1/S   (device-eager: x.div(python_scalar) == x * (1/S))

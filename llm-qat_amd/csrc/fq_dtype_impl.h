@@ -31,6 +31,60 @@ static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #undef R
 }
 
+template <int DT, int AC, bool NTL, bool NTS>
+static void launch_reg_ac(const RowArgs& a, int64_t nvec, hipStream_t st) {
+#define R(TPR, V)                                                                                                            \
+    case V:                                                                                                                  \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, false, false, NTL, NTS, false, AC>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),  \
+                  (TPR == 64 ? 256 : TPR), st, a);                                                                           \
+        break;
+    if (nvec <= 192) {
+        switch ((int)((nvec + 63) / 64)) { R(64, 1) R(64, 2) R(64, 3) }
+    } else if (nvec <= 384) {
+        switch ((int)((nvec + 127) / 128)) { R(128, 2) R(128, 3) }
+    } else if (nvec <= 768) {
+        switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) }
+    } else if (nvec <= 4096) {
+        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+    } else {
+        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+    }
+#undef R
+}
+
+template <int DT, int AC>
+static int sym_autocast_t(RowArgs a, hipStream_t st) {
+    using T = Ty<DT>;
+    if constexpr (T::ESIZE != 2) {
+        return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
+    } else {
+        constexpr int EPV = 8;
+        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0);
+        const int64_t nvec = a.cols / EPV;
+        const int64_t bytes = a.rows * a.cols * T::ESIZE;
+        if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
+        if (vec_ok && nvec <= REG_MAX_VEC) {
+            if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
+            else if (bytes >= NT_STORE_MIN_BYTES) launch_reg_ac<DT, AC, false, true>(a, nvec, st);
+            else launch_reg_ac<DT, AC, false, false>(a, nvec, st);
+        } else if (a.mask) {
+            return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
+        } else if (a.cols <= GENERIC_MAX_COLS) {
+            if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, false, AC>), (a.rows + 3) / 4, 256, st, a);
+            else FQ_LAUNCH((row_generic_kernel<DT, 256, false, AC>), a.rows, 256, st, a);
+        } else {
+            return fail(FQ_ERR_UNSUPPORTED, "autocast arithmetic: rows longer than %lld elements are not served", (long long)GENERIC_MAX_COLS);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+        return ok();
+    }
+}
+
+template <int DT> int launch_sym_autocast(bool wide, RowArgs a, hipStream_t st) {
+    return wide ? sym_autocast_t<DT, 2>(a, st) : sym_autocast_t<DT, 1>(a, st);
+}
+
 template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
@@ -192,6 +246,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
 
 #define FQ_INSTANTIATE(DT)                                                                                      \
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
+    template int launch_sym_autocast<DT>(bool, RowArgs, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
     template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t); \

@@ -78,9 +78,10 @@ template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g
 //   Out-of-range slots re-load the row's last vector (idempotent for max/min), so no load
 //   sits behind a branch; only stores are predicated.
 // ------------------------------------------------------------------------------------
-template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false>
+template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false, int AC = 0>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
     using T = Ty<DT>;
+    static_assert(AC == 0 || (!ASYM && !DBG && T::ESIZE == 2), "autocast arithmetic: Sym on 16-bit tensors");
     constexpr int EPV = 16 / T::ESIZE;
     constexpr int NW = TPR / 64;
     __shared__ uint32_t red[3][NW > 1 ? NW : 1];
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         }
         const uint32_t mbits = block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]);
         const float m = as_f(mbits);
-        sr = sym_row<DT>(m, a.sym);
+        if constexpr (AC == 0) sr = sym_row<DT>(m, a.sym);
+        else sr = sym_row_autocast<DT>(m, a.sym.qmax);
         ub = m;
         lb = -m;
         if (t == 0) {
@@ -188,6 +190,28 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             if (sym_clip) ste_mask_store<EPV, true>(f, a.lo, a.hi, gw, t & 63);
             else ste_mask_store<EPV, false>(f, a.lo, a.hi, gw, t & 63);
         }
+        if constexpr (AC != 0) {  // fp32 arithmetic behind the reciprocal, as autocast makes the reference do
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] = sym_elem_autocast(f[e], sr);
+            if constexpr (AC == 2) {  // fp32 result: two 16-byte stores per input vector
+                uint4* y32 = (uint4*)((char*)a.y + row * a.cols * 4);
+                if (v < nvec) {
+                    st16<NTS>(&y32[2 * v], make_uint4(as_u(f[0]), as_u(f[1]), as_u(f[2]), as_u(f[3])));
+                    st16<NTS>(&y32[2 * v + 1], make_uint4(as_u(f[4]), as_u(f[5]), as_u(f[6]), as_u(f[7])));
+                }
+            } else {  // rounded once to the tensor dtype
+                uint32_t o[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float fd[T::EPD];
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
+                    o[d] = T::pack(fd);
+                }
+                if (v < nvec) st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
+            }
+            continue;
+        }
         uint32_t o[4];
         int32_t ib[EPV];
 #pragma unroll
@@ -230,9 +254,10 @@ template <int DT> __device__ __forceinline__ float asym_elem(float x, const Asym
 }
 
 // Any width / alignment; TPR threads sweep the row twice.
-template <int DT, int TPR, bool ASYM>
+template <int DT, int TPR, bool ASYM, int AC = 0>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowArgs a) {
     using T = Ty<DT>;
+    static_assert(AC == 0 || (!ASYM && T::ESIZE == 2), "autocast arithmetic: Sym on 16-bit tensors");
     constexpr int NW = TPR / 64;
     __shared__ uint32_t red[3][NW > 1 ? NW : 1];
     int64_t row;
@@ -257,7 +282,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
             acc = acc > b ? acc : b;
         }
         const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
-        sr = sym_row<DT>(m, a.sym);
+        if constexpr (AC == 0) sr = sym_row<DT>(m, a.sym);
+        else sr = sym_row_autocast<DT>(m, a.sym.qmax);
         if (t == 0) {
             if (a.scale) a.scale[row] = sr.s;
             if (a.bounds) {
@@ -295,7 +321,13 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
         const float v = T::load1(a.x, base + c);
         int32_t* ip = a.idx ? a.idx + base + c : nullptr;
         float o;
-        if constexpr (!ASYM) o = sym_elem<DT, false>(v, sr, ip);
+        if constexpr (AC != 0) {
+            o = sym_elem_autocast(v, sr);
+            if constexpr (AC == 2) {
+                ((float*)a.y)[base + c] = o;
+                continue;
+            }
+        } else if constexpr (!ASYM) o = sym_elem<DT, false>(v, sr, ip);
         else o = asym_elem<DT>(v, ar, a.asym, ip);
         T::store1(a.y, base + c, o);
     }

@@ -183,6 +183,54 @@ def train_backward(grad_output, side, rows, cols, lo, hi):
     return gx
 
 
+def autocast_active(x):
+    """True when the reference's op chain would run its fp32-promoted arithmetic on x: a 16-bit CUDA tensor inside
+    torch.autocast("cuda") (`reciprocal`, i.e. the `int / Tensor` of utils_quant.py:71, is on autocast's fp32 list)."""
+    return x.dtype in (torch.bfloat16, torch.float16) and x.is_cuda and torch.is_autocast_enabled("cuda")
+
+
+def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=None):
+    """SymQuantizer.forward with autocast arithmetic (fq_sym_fwd_autocast).
+    train: None (no side outputs) | "bounds" | "mask".  -> (y, side or bounds or None, rows, cols, got)
+    where got is the side information actually produced ("mask", "bounds" or None)."""
+    code = _prep(x, "sym_quantize[autocast]")
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    if x.numel() == 0:
+        return torch.empty(x.shape, dtype=torch.float32 if wide else x.dtype, device=x.device), None, rows, cols, None
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.float32 if wide else x.dtype, device=x.device)
+    L = _lib.lib()
+    side, got = None, None
+    with _DeviceOf(x):
+        st = _stream(x)
+        rc = _lib.ERR_UNSUPPORTED
+        if train == "mask" and xc is x:
+            mbytes = _mask_bytes(rows, cols, code)
+            if mbytes:
+                side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
+                sp = side.data_ptr()
+                rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
+                                           sp, sp + rows * 8, mbytes, st)
+                got = "mask"
+        if rc == _lib.ERR_UNSUPPORTED:
+            side, got = None, None
+            bptr = None
+            if train in ("mask", "bounds"):
+                side = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+                bptr, got = side.data_ptr(), "bounds"
+            rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
+                                       bptr, None, 0, st)
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise NotImplementedError("sym_quantize under autocast: rows longer than 32768 elements are not served: "
+                                  + _lib.lib().fq_last_error().decode(errors="replace"))
+    _lib.check(rc, "sym_quantize[autocast]")
+    if xc is not x:
+        out = torch.empty_like(x, dtype=y.dtype)  # keeps the input's strides, as the reference's elementwise ops do
+        out.copy_(y)
+        y = out
+    return y, side, rows, cols, got
+
+
 def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
     not served by the STE-mask path (the caller then uses the general forward + x-based backward)."""

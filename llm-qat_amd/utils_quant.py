@@ -54,7 +54,29 @@ class _FakeQuantFunction(torch.autograd.Function):
     _kind = None
 
     @staticmethod
-    def _fwd(kind, ctx, input, clip_val, num_bits, layerwise):
+    def _fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow):
+        """The reference under torch.autocast("cuda"): fp32 arithmetic behind the reciprocal, fp32 result (or, for
+        QuantizeLinear's own operands, that result rounded once -- exactly what F.linear's autocast cast does next)."""
+        mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
+        lo, hi = _clip_pair(clip_val)
+        out, side, rows, cols, got = ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow, lo=lo, hi=hi,
+                                                              train=None if mode == "plain" else mode)
+        ctx.grad_dtype = input.dtype  # the engine casts the reference's fp32 gradient to the input dtype; do it up front
+        ctx.clip, ctx.rows_cols, ctx.row_bounds = (lo, hi), (rows, cols), None
+        if got == "mask":
+            ctx.fq_mode, ctx.side = "mask", side
+            return out
+        ctx.save_for_backward(input, clip_val)
+        ctx.fq_mode = "plain"
+        if got == "bounds":
+            ctx.fq_mode, ctx.row_bounds = "bounds", side
+        return out
+
+    @staticmethod
+    def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False):
+        ctx.grad_dtype = None
+        if kind == "sym" and ops.autocast_active(input):
+            return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
         mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
         ctx.fq_mode = "plain"
         ctx.row_bounds = None
@@ -79,6 +101,8 @@ class _FakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
+        if ctx.grad_dtype is not None and grad_output.dtype != ctx.grad_dtype:
+            grad_output = grad_output.to(ctx.grad_dtype)  # autocast: fp32 grad of the fp32 output; zeroing commutes with the cast
         if ctx.fq_mode == "mask":
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
@@ -99,6 +123,15 @@ class SymQuantizer(_FakeQuantFunction):
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
         return _FakeQuantFunction._fwd("sym", ctx, input, clip_val, num_bits, layerwise)
+
+
+class _SymQuantizerOperand(_FakeQuantFunction):
+    """SymQuantizer for QuantizeLinear's own operands: identical, except that under autocast it hands F.linear the
+    fp32 result already rounded to the operand dtype (the value F.linear's autocast cast would produce from it)."""
+
+    @staticmethod
+    def forward(ctx, input, clip_val, num_bits, layerwise):
+        return _FakeQuantFunction._fwd("sym", ctx, input, clip_val, num_bits, layerwise, narrow=True)
 
 
 class AsymQuantizer(_FakeQuantFunction):
@@ -163,12 +196,14 @@ def enable_weight_quant_cache(flag=True, persistent=False):
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
+    if quantizer is SymQuantizer:
+        quantizer = _SymQuantizerOperand
     if not _SHARE_ACT:
         return quantizer.apply(x, _CLIP, num_bits, layerwise)
     cache = getattr(_tls, "act", None)
     if cache is None:
         cache = _tls.act = {}
-    key = (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics())
+    key = (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(x))
     ent = cache.get(key)
     if ent is not None:
         rin, ver_in, y, ver_out, epoch = ent
@@ -232,8 +267,8 @@ class QuantizeLinear(nn.Linear):
 
     def _quantized_weight(self):
         w = self.weight
-        if not _WEIGHT_CACHE or not w.is_cuda:
-            return SymQuantizer.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
+        if not _WEIGHT_CACHE or not w.is_cuda or ops.autocast_active(w):
+            return _SymQuantizerOperand.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics())
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:

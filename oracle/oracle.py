@@ -34,7 +34,8 @@ def lib():
         L.fqo_asym_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32]
         L.fqo_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32, i32]
         L.fqo_w12_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32]
-        for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version):
+        L.fqo_sym_fwd_autocast.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32]
+        for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version, L.fqo_sym_fwd_autocast):
             f.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -62,6 +63,17 @@ def sym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
     if rc:
         raise ValueError(f"fqo_sym_fwd rc={rc}")
     return y, idx, scale
+
+
+def sym_fwd_autocast(x, rows, cols, bits, dtype, wide=True):
+    """SymQuantizer under CUDA autocast on a 16-bit tensor -> (y float32 if wide else dtype bits, idx)."""
+    x = _check(x, dtype)
+    y = np.empty(x.shape, np.float32 if wide else np.uint16)
+    idx = np.empty(x.shape, np.int32)
+    rc = lib().fqo_sym_fwd_autocast(_p(x), _p(y), _p(idx), rows, cols, bits, DTYPES[dtype], 1 if wide else 0)
+    if rc:
+        raise ValueError(f"fqo_sym_fwd_autocast rc={rc}")
+    return y, idx
 
 
 def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):

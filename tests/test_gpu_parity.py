@@ -145,7 +145,7 @@ def make_input(rng, shape, dtype, style):
         x = rng.standard_normal(shape).astype(np.float32)
         x[rng.random(shape) < 1e-3] *= 20.0
     else:  # mixed row scales
-        x = rng.standard_normal(shape).astype(np.float32) * rng.choice([1e-6, 1e-4, 0.02, 1.0, 50.0], size=(shape[0], 1)).astype(np.float32)
+        x = rng.standard_normal(shape).astype(np.float32) * rng.choice([1e-6, 1e-4, 0.02, 1.0, 50.0], size=tuple(shape[:-1]) + (1,)).astype(np.float32)
     t = torch.from_numpy(x).to(TD[dtype])
     return np_from(t), t.cuda()
 
@@ -441,3 +441,84 @@ def test_randomized_stress_all_paths(ops):
                 assert bits_equal(np_from(xr.grad), want_g, dtype), f"{tag} {mode} grad: " + mismatch_report(np_from(xr.grad), want_g, dtype)
     finally:
         llm_qat_amd.set_backward_mode(prev)
+
+
+# ------------------------------------------------------------------------------------------
+# autocast: LLM-QAT trains under torch.autocast("cuda", bf16); `reciprocal` is on autocast's fp32 list, so the
+# reference's SymQuantizer computes in fp32 behind it and RETURNS fp32 for a 16-bit input.  Truth = the live ATen chain.
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_sym_under_autocast_vs_live_aten(ops, dtype):
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import SymQuantizer, _SymQuantizerOperand
+    from oracle import eager_chain as E
+    rng = np.random.default_rng(31)
+    clip = torch.tensor([-2.0, 2.0])
+    prev = llm_qat_amd.get_backward_mode()
+    try:
+        for shape in [(16, 256), (8, 4096), (3, 11008), (5, 33), (2, 3, 64), (4, 4104), (2, 20000)]:
+            for style, bits in (("act", 8), ("weight", 4), ("mixed", 8), ("mixed", 16)):
+                x_np, x = make_input(rng, shape, dtype, style)
+                g = torch.randn(shape, device="cuda")
+                with torch.autocast("cuda", dtype=TD[dtype]):
+                    xr = x.clone().requires_grad_(True)
+                    ref = E.EagerSym.apply(xr, clip, bits, False)
+                ref.backward(g)
+                assert ref.dtype == torch.float32 and xr.grad.dtype == TD[dtype]
+                rows, cols = O.rows_cols(shape, False)
+                yo, _ = O.sym_fwd_autocast(x_np, rows, cols, bits, dtype, wide=True)
+                tag = f"{dtype} {shape} {style} b{bits}"
+                assert bits_equal(np_from(ref).reshape(yo.shape), yo, "fp32"), tag + " oracle vs live ATen"
+                for mode in ("mask", "bounds", "plain"):
+                    llm_qat_amd.set_backward_mode(mode)
+                    with torch.autocast("cuda", dtype=TD[dtype]):
+                        xo = x.clone().requires_grad_(True)
+                        y = SymQuantizer.apply(xo, clip, bits, False)
+                        xn = x.clone().requires_grad_(True)
+                        yn = _SymQuantizerOperand.apply(xn, clip, bits, False)
+                    assert y.dtype == torch.float32 and bits_equal(np_from(y), np_from(ref), "fp32"), f"{tag} {mode} wide: {mismatch_report(np_from(y), np_from(ref), 'fp32')}"
+                    assert yn.dtype == TD[dtype] and bits_equal(np_from(yn), np_from(ref.to(TD[dtype])), dtype), f"{tag} {mode} narrow"
+                    y.backward(g)
+                    yn.backward(g.to(TD[dtype]))
+                    assert bits_equal(np_from(xo.grad), np_from(xr.grad), dtype), f"{tag} {mode} grad"
+                    assert bits_equal(np_from(xn.grad), np_from(xr.grad), dtype), f"{tag} {mode} narrow grad"
+        # fp32 tensors are untouched by autocast; Asym has no autocast-listed op
+        x32 = torch.randn(8, 512, device="cuda")
+        xb = torch.randn(8, 512, device="cuda").to(TD[dtype])
+        with torch.autocast("cuda", dtype=TD[dtype]):
+            assert torch.equal(SymQuantizer.apply(x32, clip, 8, False), E.sym_forward(x32, 8))
+            llm_qat_amd.set_semantics("device_eager")
+            from llm_qat_amd.utils_quant import AsymQuantizer
+            ya, ye = AsymQuantizer.apply(xb, clip, 8, False), E.asym_forward(xb, 8)
+            assert ya.dtype == ye.dtype == TD[dtype] and torch.equal(ya, ye)
+    finally:
+        llm_qat_amd.set_backward_mode(prev)
+        llm_qat_amd.set_semantics("cpu_eager")
+
+
+def test_quantize_linear_under_autocast_vs_live_aten(ops):
+    """the module as kd_trainer runs it (bf16 weights, bf16 autocast): outputs and both gradients bit-identical to the
+    eager chain, although the drop-in skips the fp32 materialisation of the quantized operands"""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    import tiny_llama as TL
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    EQ = TL.EagerQuant()
+    torch.manual_seed(3)
+    for wb, ab in ((4, 8), (8, 8), (4, 16)):
+        ours = QuantizeLinear(1024, 512, w_bits=wb, a_bits=ab).cuda().bfloat16()
+        ref = EQ.QuantizeLinear(1024, 512, w_bits=wb, a_bits=ab).cuda().bfloat16()
+        with torch.no_grad():
+            ref.weight.copy_(ours.weight)
+            ours.weight[3, 5] = ref.weight[3, 5] = 2.5
+        xs = (torch.randn(4, 64, 1024, device="cuda") * 1.5).bfloat16()
+        res = []
+        for m in (ours, ref):
+            x = xs.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x)
+                loss = out.float().square().mean()
+            loss.backward()
+            res.append((out.detach(), x.grad, m.weight.grad))
+        for a, b in zip(res[0], res[1]):
+            assert a.dtype == b.dtype and torch.equal(a, b), (wb, ab)

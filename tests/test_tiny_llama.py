@@ -79,3 +79,23 @@ def test_dropin_is_bit_identical_to_eager_chain_on_gpu(tag, dtype):
             assert torch.equal(p.grad, q.grad), n
     finally:
         llm_qat_amd.set_semantics("cpu_eager")
+
+
+@pytest.mark.gpu
+def test_dropin_is_bit_identical_under_autocast():
+    """kd_trainer.py:106 runs the step under HF's bf16 autocast: the quantizers are not autocast ops, so they must run
+    in the dtype they are handed (fp32 master weights here) -- exactly as the eager chain does."""
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+    ours = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).float()).cuda()
+    ref = TL.load_deterministic(TL.TinyLlama(TL.EagerQuant(), w_bits=4, a_bits=8, kv_bits=4).float()).cuda()
+    outs = []
+    for m in (ours, ref):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss, logits = m(ids, labels=ids)
+        loss.backward()
+        outs.append((loss.detach(), logits.detach()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for (n, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
+        assert p.grad.dtype == torch.float32 and torch.equal(p.grad, q.grad), n

@@ -132,6 +132,21 @@ class Workload:
         if rc:
             self._lib.check(rc, "fq_sym_fwd")
 
+    # SymQuantizer as the reference runs it under torch.autocast("cuda", bf16) (LLM-QAT's training configuration):
+    # fp32 arithmetic behind the reciprocal; narrow = rounded once to bf16 (QuantizeLinear operands), wide = fp32 result
+    def fwd_autocast(self, s, leg, wide):
+        x, y, b, m, bits = (s["w"], s["yw"], s["bw"], s["mw"], 4) if leg == "w" else (s["a"], s["ya"], s["ba"], s["ma"], 8)
+        if wide:
+            if not hasattr(self, "y32"):
+                self.y32 = self.torch.empty(self.rows, self.cols, device=x.device)
+            rc = self.L.fq_sym_fwd_autocast(x.data_ptr(), self.y32.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16, 1, -2.0, 2.0,
+                                            b.data_ptr(), None, 0, self.stream)
+        else:
+            rc = self.L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16, 0, -2.0, 2.0,
+                                            b.data_ptr(), m.data_ptr(), self.mask_bytes, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_sym_fwd_autocast")
+
     def bwd_xread(self, s, leg):
         g, x, gx = (s["gw"], s["w"], s["gxw"]) if leg == "w" else (s["ga"], s["a"], s["gxa"])
         rc = self.L.fq_ste_bwd(g.data_ptr(), x.data_ptr(), gx.data_ptr(), self.n, -2.0, 2.0, self._lib.DTYPE_BF16, self.stream)
@@ -401,6 +416,12 @@ def main():
             "ste_bwd_a8_xread": (lambda s: wl.bwd_xread(s, "a"), nb * BWD_BYTES_PER_ELEM),
         }
         out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in alt.items()]
+        ac = {
+            "sym_fwd_w4_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "w", False), nb * FWD_BYTES_PER_ELEM),
+            "sym_fwd_a8_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "a", False), nb * FWD_BYTES_PER_ELEM),
+            "sym_fwd_a8_autocast_fp32_out": (lambda s: wl.fwd_autocast(s, "a", True), nb * 6),  # read 2 + write 4 B/elem
+        }
+        out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ac.items()]
         dom = max(kernels, key=lambda e: e["us_per_launch"])
         out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic") if k in dom}
         out["roofline"].update({k: dom[k] for k in ("kernel", "traffic_gbs", "traffic_frac", "us_per_launch") if k in dom})

@@ -52,6 +52,19 @@ static void launch_reg_ac(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #undef R
 }
 
+template <int DT, int TPR, bool NTL, bool NTS>
+static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
+    const int64_t grid = TPR == 64 ? (a.rows + 3) / 4 : a.rows;
+    constexpr int BLOCK = TPR == 64 ? 256 : TPR;
+    switch (hpt) {
+#define H(N) \
+    case N: FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS>), grid, BLOCK, st, a); break;
+        H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(8)
+#undef H
+        default: break;
+    }
+}
+
 template <int DT, int AC>
 static int sym_autocast_t(RowArgs a, hipStream_t st) {
     using T = Ty<DT>;
@@ -63,6 +76,25 @@ static int sym_autocast_t(RowArgs a, hipStream_t st) {
         const int64_t nvec = a.cols / EPV;
         const int64_t bytes = a.rows * a.cols * T::ESIZE;
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
+        if constexpr (AC == 2) {
+            // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced; no STE mask on this path
+            const int64_t nh = a.cols / 4;
+            if (!a.mask && aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8) {
+                const bool nts = 3 * bytes >= NT_STORE_MIN_BYTES, ntl = bytes >= NT_LOAD_MIN_BYTES;
+#define W(TPR)                                                                                          \
+    {                                                                                                   \
+        const int hpt = (int)((nh + TPR - 1) / TPR);                                                    \
+        if (ntl) launch_wide<DT, TPR, true, true>(a, hpt, st);                                          \
+        else if (nts) launch_wide<DT, TPR, false, true>(a, hpt, st);                                    \
+        else launch_wide<DT, TPR, false, false>(a, hpt, st);                                            \
+    }
+                if (nh <= 512) W(64) else if (nh <= 2048) W(256) else W(1024)
+#undef W
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+                return ok();
+            }
+        }
         if (vec_ok && nvec <= REG_MAX_VEC) {
             if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
             else if (bytes >= NT_STORE_MIN_BYTES) launch_reg_ac<DT, AC, false, true>(a, nvec, st);

@@ -204,7 +204,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     with _DeviceOf(x):
         st = _stream(x)
         rc = _lib.ERR_UNSUPPORTED
-        if train == "mask" and xc is x:
+        if train == "mask" and xc is x and not wide:  # the fp32-result kernel records bounds only (see fq_kernels.h)
             mbytes = _mask_bytes(rows, cols, code)
             if mbytes:
                 side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)

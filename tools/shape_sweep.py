@@ -65,12 +65,22 @@ def main():
                 us_b = t(lambda s: chk(L.fq_ste_bwd_mask(s["g"].data_ptr(), s["gx"].data_ptr(), rows, cols, -2.0, 2.0, s["b"].data_ptr(),
                                                          s["m"].data_ptr(), s["mb"], code, st)))
                 us_bx = t(lambda s: chk(L.fq_ste_bwd(s["g"].data_ptr(), s["x"].data_ptr(), s["gx"].data_ptr(), n, -2.0, 2.0, code, st)))
+                us_acn = us_acw = None
+                if kind == "sym" and esz == 2:   # the reference's arithmetic under torch.autocast (fp32 behind the reciprocal)
+                    y32 = torch.empty(rows, cols, device=dev)
+                    us_acn = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, bits, code, 0, -2.0, 2.0,
+                                                                    s["b"].data_ptr(), s["m"].data_ptr() if s["mb"] else None, s["mb"], st)))
+                    us_acw = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), y32.data_ptr(), rows, cols, bits, code, 1, -2.0, 2.0,
+                                                                    s["b"].data_ptr(), None, 0, st)))
                 row = dict(shape=label, dtype=str(dtype).split(".")[-1], kind=kind, bits=bits, elems=n, fwd_us=round(us_f, 2),
                            bwd_mask_us=round(us_b, 2), bwd_xread_us=round(us_bx, 2),
+                           fwd_autocast_narrow_us=None if us_acn is None else round(us_acn, 2),
+                           fwd_autocast_wide_us=None if us_acw is None else round(us_acw, 2),
                            fwd_gbs=round(n * 2 * esz / us_f / 1e3, 1), fwd_bwd_gelems=round(n / (us_f + us_b) / 1e3, 1))
                 out.append(row)
                 print(f"{label:26s} {row['dtype']:8s} {kind:4s} b{bits}  fwd {us_f:7.2f} us ({row['fwd_gbs']:7.1f} GB/s)  "
-                      f"bwd(mask) {us_b:7.2f} us  bwd(x) {us_bx:7.2f} us  fwd+bwd {row['fwd_bwd_gelems']:6.1f} Gelem/s", flush=True)
+                      f"bwd(mask) {us_b:7.2f} us  bwd(x) {us_bx:7.2f} us  fwd+bwd {row['fwd_bwd_gelems']:6.1f} Gelem/s"
+                      + (f"  | autocast fwd narrow {us_acn:7.2f} wide {us_acw:7.2f} us" if us_acn is not None else ""), flush=True)
             del sets
             torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

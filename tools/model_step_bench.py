@@ -29,13 +29,17 @@ def build(quant, layers, wb, ab, kvb):
     return m
 
 
+AUTOCAST = False
+
+
 def step(model, ids, ckpt):
     model.zero_grad(set_to_none=True)
-    h = model.model.embed_tokens(ids)
-    for layer in model.model.layers:
-        h = checkpoint(layer, h, use_reentrant=False) if ckpt else layer(h)
-    logits = model.lm_head(model.model.norm(h))
-    loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), ids[..., 1:].reshape(-1))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=AUTOCAST):   # LLM-QAT trains under bf16 autocast (--bf16 True)
+        h = model.model.embed_tokens(ids)
+        for layer in model.model.layers:
+            h = checkpoint(layer, h, use_reentrant=False) if ckpt else layer(h)
+        logits = model.lm_head(model.model.norm(h))
+        loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), ids[..., 1:].reshape(-1))
     loss.backward()
     return loss
 
@@ -55,7 +59,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--autocast", action="store_true", help="run the step under torch.autocast(cuda, bf16), as run_train.sh does")
     args = ap.parse_args()
+    global AUTOCAST
+    AUTOCAST = args.autocast
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
 
@@ -79,11 +86,11 @@ def main():
                 llm_qat_amd.enable_weight_quant_cache(wcache)
                 ms = timed(lambda: step(model, ids, ckpt), args.iters)
                 llm_qat_amd.enable_weight_quant_cache(False)
-                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, impl=label, ms_per_step=round(ms, 2), layers=args.layers))
+                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers))
                 print(rows[-1], flush=True)
                 del model
                 torch.cuda.empty_cache()
-    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "model_step_bench.json"), "w"), indent=1)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "model_step_bench_autocast.json" if AUTOCAST else "model_step_bench.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

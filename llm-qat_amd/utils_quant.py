@@ -267,9 +267,10 @@ class QuantizeLinear(nn.Linear):
 
     def _quantized_weight(self):
         w = self.weight
-        if not _WEIGHT_CACHE or not w.is_cuda or ops.autocast_active(w):
+        if not _WEIGHT_CACHE or not w.is_cuda:
             return _SymQuantizerOperand.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
-        key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics())
+        ac = ops.autocast_active(w)
+        key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics(), ac)
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:
             cached = ent[1]
@@ -277,13 +278,22 @@ class QuantizeLinear(nn.Linear):
                 self._fq_wcache = None  # second use within the step (the checkpoint recompute): done with it
         else:
             rc = ops.rows_cols(tuple(w.shape), self.weight_layerwise)
-            res = ops.quantize_train("sym", w, self.w_bits, self.weight_layerwise, -2.0, 2.0) if _BACKWARD_MODE == "mask" else None
-            if res is not None:
-                y, bounds, mask = res
-            elif _BACKWARD_MODE == "plain":
-                y, bounds, mask = ops.sym_quantize(w, self.w_bits, self.weight_layerwise), None, None
+            bounds = mask = None
+            if ac:  # autocast arithmetic, result rounded once to the weight dtype (see _SymQuantizerOperand)
+                y, side, rows, _, got = ops.sym_forward_autocast(w, self.w_bits, self.weight_layerwise, wide=False,
+                                                                 train=None if _BACKWARD_MODE == "plain" else _BACKWARD_MODE)
+                if got == "mask":
+                    bounds, mask = side[: rows * 8].view(torch.float32).view(rows, 2), side[rows * 8:]
+                elif got == "bounds":
+                    bounds = side
             else:
-                (y, bounds), mask = ops.sym_quantize(w, self.w_bits, self.weight_layerwise, want_bounds=True), None
+                res = ops.quantize_train("sym", w, self.w_bits, self.weight_layerwise, -2.0, 2.0) if _BACKWARD_MODE == "mask" else None
+                if res is not None:
+                    y, bounds, mask = res
+                elif _BACKWARD_MODE == "plain":
+                    y = ops.sym_quantize(w, self.w_bits, self.weight_layerwise)
+                else:
+                    y, bounds = ops.sym_quantize(w, self.w_bits, self.weight_layerwise, want_bounds=True)
             cached = (y, bounds, mask, rc)
             self._fq_wcache = (key, cached)
         if torch.is_grad_enabled() and w.requires_grad:

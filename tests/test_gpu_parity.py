@@ -522,3 +522,39 @@ def test_quantize_linear_under_autocast_vs_live_aten(ops):
             res.append((out.detach(), x.grad, m.weight.grad))
         for a, b in zip(res[0], res[1]):
             assert a.dtype == b.dtype and torch.equal(a, b), (wb, ab)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "fp16"])
+def test_device_eager_on_adversarial_rows_vs_live_aten(ops, dtype):
+    """NaN / Inf / denormal / tiny-max / tie rows (the reference fixtures' adversarial inputs) through the kernels in
+    device-eager mode against the live ATen chain on this GPU -- with and without autocast."""
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
+    from oracle import eager_chain as E
+    G = golden("sym_fwd.npz")
+    clip = torch.tensor([-2.0, 2.0])
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        bad = []
+        for bits in (4, 8, 16):
+            c = next(c for c in G.cases if c["name"] == f"sym_{dtype}_b{bits}_adversarial")
+            x = dev_from(G.arr(c, "x"), dtype)
+            names = c["row_names"]
+            for label, ours, ref in (("sym", SymQuantizer.apply(x, clip, bits, False), E.sym_forward(x, bits)),
+                                     ("asym", AsymQuantizer.apply(x, clip, bits, False), E.asym_forward(x, bits))):
+                a, b = np_from(ours), np_from(ref)
+                for r, nm in enumerate(names):
+                    if label == "asym" and nm in ("neg_zero",):
+                        continue   # which of -0.0 / +0.0 is "the" minimum is unspecified
+                    if not bits_equal(a[r], b[r], dtype):
+                        bad.append(f"{label} b{bits} row {nm}: {mismatch_report(a[r], b[r], dtype)}")
+            if dtype != "fp32":
+                with torch.autocast("cuda", dtype=TD[dtype]):
+                    ours, ref = SymQuantizer.apply(x, clip, bits, False), E.sym_forward(x, bits)
+                a, b = np_from(ours), np_from(ref)
+                for r, nm in enumerate(names):
+                    if not bits_equal(a[r], b[r], "fp32"):
+                        bad.append(f"autocast sym b{bits} row {nm}: {mismatch_report(a[r], b[r], 'fp32')}")
+        assert not bad, "\\n".join(bad[:20])
+    finally:
+        llm_qat_amd.set_semantics("cpu_eager")

@@ -51,8 +51,6 @@ def _clip_pair(clip_val):
 
 
 class _FakeQuantFunction(torch.autograd.Function):
-    _kind = None
-
     @staticmethod
     def _fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow):
         """The reference under torch.autocast("cuda"): fp32 arithmetic behind the reciprocal, fp32 result (or, for

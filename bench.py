@@ -140,10 +140,10 @@ class Workload:
             if not hasattr(self, "y32"):
                 self.y32 = self.torch.empty(self.rows, self.cols, device=x.device)
             rc = self.L.fq_sym_fwd_autocast(x.data_ptr(), self.y32.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16, 1, -2.0, 2.0,
-                                            b.data_ptr(), None, 0, self.stream)
+                                            b.data_ptr(), None, 0, None, 0, self.stream)
         else:
             rc = self.L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), self.rows, self.cols, bits, self._lib.DTYPE_BF16, 0, -2.0, 2.0,
-                                            b.data_ptr(), m.data_ptr(), self.mask_bytes, self.stream)
+                                            b.data_ptr(), m.data_ptr(), self.mask_bytes, None, 0, self.stream)
         if rc:
             self._lib.check(rc, "fq_sym_fwd_autocast")
 

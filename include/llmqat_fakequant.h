@@ -154,10 +154,12 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
  *                autocast cast makes of it next, so QuantizeLinear can skip the fp32 round trip (2 instead of 4+4+2 B/elem)
  *   row_bounds_out / mask_out  optional training-mode outputs, as in fq_sym_fwd_train (mask_out needs row_bounds_out);
  *             the backward is fq_ste_bwd_mask / fq_ste_bwd on the input dtype (cast an fp32 grad_output first).
- * Returns FQ_ERR_UNSUPPORTED for rows longer than 32768 elements (or, with a mask, shapes fq_ste_mask_bytes rejects).
+ *   workspace  fq_rowwise_workspace_bytes(rows, cols, dtype) bytes (only rows longer than 32768 elements use it)
+ * Returns FQ_ERR_UNSUPPORTED when a mask is requested for a shape fq_ste_mask_bytes rejects or for misaligned rows.
  */
 int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
-                        float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+                        float* row_bounds_out, void* mask_out, size_t mask_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /*
  * QuantizeLinear's 1- and 2-bit weight branches -- models/utils_quant.py:202-242, elementwise part:

@@ -63,7 +63,7 @@ def _bind(L):
     L.fq_ste_bwd_mask.restype = i32
     L.fq_w12_fwd.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
     L.fq_w12_fwd.restype = i32
-    L.fq_sym_fwd_autocast.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp]
+    L.fq_sym_fwd_autocast.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp, sz, vp]
     L.fq_sym_fwd_autocast.restype = i32
     return L
 

@@ -177,7 +177,8 @@ FQ_API int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols,
 }
 
 FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
-                               float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
+                               float* row_bounds_out, void* mask_out, size_t mask_bytes, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16)
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors (fp32 tensors are unaffected by autocast)");
     if (bits < 2 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [2, 31]", bits);
@@ -198,7 +199,8 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
         a.hi = host_rb(hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
-    return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide_out != 0, a, st) : launch_sym_autocast<F16>(wide_out != 0, a, st);
+    return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide_out != 0, a, workspace, workspace_bytes, st)
+                                  : launch_sym_autocast<F16>(wide_out != 0, a, workspace, workspace_bytes, st);
 }
 
 FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,

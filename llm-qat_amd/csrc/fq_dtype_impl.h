@@ -66,7 +66,7 @@ static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
 }
 
 template <int DT, int AC>
-static int sym_autocast_t(RowArgs a, hipStream_t st) {
+static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
@@ -104,8 +104,18 @@ static int sym_autocast_t(RowArgs a, hipStream_t st) {
         } else if (a.cols <= GENERIC_MAX_COLS) {
             if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, false, AC>), (a.rows + 3) / 4, 256, st, a);
             else FQ_LAUNCH((row_generic_kernel<DT, 256, false, AC>), a.rows, 256, st, a);
-        } else {
-            return fail(FQ_ERR_UNSUPPORTED, "autocast arithmetic: rows longer than %lld elements are not served", (long long)GENERIC_MAX_COLS);
+        } else {  // very long rows (layerwise): two passes -- |x| max per row through atomics, then apply
+            if (!ws || wsb < (size_t)a.rows * 8)
+                return fail(FQ_ERR_WORKSPACE, "two-pass path needs %zu workspace bytes, got %zu", (size_t)a.rows * 8, wsb);
+            if (hipMemsetAsync(ws, 0, (size_t)a.rows * 8, st) != hipSuccess) return fail(FQ_ERR_LAUNCH, "hipMemsetAsync failed");
+            uint32_t* w = (uint32_t*)ws;
+            const bool svec = aligned16(a.x) && a.cols % EPV == 0;
+            const int64_t sch = svec ? tp_chunk_elems<DT, true>() : tp_chunk_elems<DT, false>();
+            const int64_t schunks = (a.cols + sch - 1) / sch, ach = (int64_t)TP_THREADS * TP_EPT, achunks = (a.cols + ach - 1) / ach;
+            if (a.rows * schunks > 0x7FFFFFFF || a.rows * achunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
+            if (svec) FQ_LAUNCH((stats_kernel<DT, false, true>), a.rows * schunks, TP_THREADS, st, a, w, schunks);
+            else FQ_LAUNCH((stats_kernel<DT, false, false>), a.rows * schunks, TP_THREADS, st, a, w, schunks);
+            FQ_LAUNCH((apply_autocast_kernel<DT, AC == 2>), a.rows * achunks, TP_THREADS, st, a, (const uint32_t*)w, achunks);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
@@ -113,8 +123,8 @@ static int sym_autocast_t(RowArgs a, hipStream_t st) {
     }
 }
 
-template <int DT> int launch_sym_autocast(bool wide, RowArgs a, hipStream_t st) {
-    return wide ? sym_autocast_t<DT, 2>(a, st) : sym_autocast_t<DT, 1>(a, st);
+template <int DT> int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t wsb, hipStream_t st) {
+    return wide ? sym_autocast_t<DT, 2>(a, ws, wsb, st) : sym_autocast_t<DT, 1>(a, ws, wsb, st);
 }
 
 template <int DT, bool ASYM, bool FAST>
@@ -278,7 +288,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
 
 #define FQ_INSTANTIATE(DT)                                                                                      \
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
-    template int launch_sym_autocast<DT>(bool, RowArgs, hipStream_t);                                           \
+    template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
     template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t); \

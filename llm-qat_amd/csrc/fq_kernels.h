@@ -581,6 +581,30 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
     }
 }
 
+// Two-pass apply with the autocast arithmetic (rows too long for the single-pass kernels: layerwise under
+// autocast).  Correctness path: element loads, one chunk of TP_THREADS * TP_EPT elements per workgroup.
+template <int DT, bool WIDE>
+__global__ __launch_bounds__(TP_THREADS) void apply_autocast_kernel(RowArgs a, const uint32_t* __restrict__ ws, int64_t chunks) {
+    using T = Ty<DT>;
+    constexpr int CH = TP_THREADS * TP_EPT;
+    const int64_t row = blockIdx.x / chunks;
+    const int64_t chunk = blockIdx.x % chunks;
+    const int64_t base = row * a.cols;
+    int64_t cend = (chunk + 1) * CH;
+    if (cend > a.cols) cend = a.cols;
+    const float m = as_f(ws[2 * row]);
+    const SymRow sr = sym_row_autocast<DT>(m, a.sym.qmax);
+    if (chunk == 0 && threadIdx.x == 0 && a.bounds) {
+        a.bounds[2 * row] = m;
+        a.bounds[2 * row + 1] = -m;
+    }
+    for (int64_t c = chunk * CH + threadIdx.x; c < cend; c += TP_THREADS) {
+        const float o = sym_elem_autocast(T::load1(a.x, base + c), sr);
+        if constexpr (WIDE) ((float*)a.y)[base + c] = o;
+        else T::store1(a.y, base + c, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // STE backward (utils_quant.py:83-87).  VEC: n is a whole number of 16-byte vectors and all
 // three pointers are 16-byte aligned; each thread moves UNR vectors of g and of x.

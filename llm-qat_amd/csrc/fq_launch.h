@@ -34,7 +34,7 @@ constexpr int64_t WS_COLS_THRESHOLD = 32768; // rows longer than this may take t
 
 template <int DT> FQ_HIDDEN int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st);
 // Sym under CUDA-autocast arithmetic (16-bit tensors only): wide = fp32 output, else rounded once to the tensor dtype
-template <int DT> FQ_HIDDEN int launch_sym_autocast(bool wide, RowArgs a, hipStream_t st);
+template <int DT> FQ_HIDDEN int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t wsb, hipStream_t st);
 template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
 template <int DT>
 FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,

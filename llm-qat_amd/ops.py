@@ -201,6 +201,9 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     y = torch.empty(xc.shape, dtype=torch.float32 if wide else x.dtype, device=x.device)
     L = _lib.lib()
     side, got = None, None
+    ws_bytes = L.fq_rowwise_workspace_bytes(rows, cols, code)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    ws_ptr = ws.data_ptr() if ws is not None else None
     with _DeviceOf(x):
         st = _stream(x)
         rc = _lib.ERR_UNSUPPORTED
@@ -210,7 +213,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
                 side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
                 sp = side.data_ptr()
                 rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
-                                           sp, sp + rows * 8, mbytes, st)
+                                           sp, sp + rows * 8, mbytes, ws_ptr, ws_bytes, st)
                 got = "mask"
         if rc == _lib.ERR_UNSUPPORTED:
             side, got = None, None
@@ -219,10 +222,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
                 side = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
                 bptr, got = side.data_ptr(), "bounds"
             rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
-                                       bptr, None, 0, st)
-    if rc == _lib.ERR_UNSUPPORTED:
-        raise NotImplementedError("sym_quantize under autocast: rows longer than 32768 elements are not served: "
-                                  + _lib.lib().fq_last_error().decode(errors="replace"))
+                                       bptr, None, 0, ws_ptr, ws_bytes, st)
     _lib.check(rc, "sym_quantize[autocast]")
     if xc is not x:
         out = torch.empty_like(x, dtype=y.dtype)  # keeps the input's strides, as the reference's elementwise ops do

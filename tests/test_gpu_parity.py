@@ -558,3 +558,43 @@ def test_device_eager_on_adversarial_rows_vs_live_aten(ops, dtype):
         assert not bad, "\\n".join(bad[:20])
     finally:
         llm_qat_amd.set_semantics("cpu_eager")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_layerwise_and_long_rows_under_autocast_vs_live_aten(ops, dtype):
+    """layerwise (one row, two-pass kernels) and rows beyond the register kernels under autocast, incl. QuantizeLinear
+    with weight_layerwise / act_layerwise -- against the live ATen chain"""
+    from llm_qat_amd.utils_quant import QuantizeLinear, SymQuantizer
+    from oracle import eager_chain as E
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    import tiny_llama as TL
+    rng = np.random.default_rng(9)
+    clip = torch.tensor([-2.0, 2.0])
+    for shape, layerwise in [((256, 1024), True), ((3, 40000), False), ((2, 70001), False), ((2, 3, 4, 5), True), ((64, 4097), True)]:
+        _, x = make_input(rng, shape, dtype, "act")
+        g = torch.randn(shape, device="cuda")
+        with torch.autocast("cuda", dtype=TD[dtype]):
+            xr = x.clone().requires_grad_(True)
+            ref = E.EagerSym.apply(xr, clip, 8, layerwise)
+            xo = x.clone().requires_grad_(True)
+            out = SymQuantizer.apply(xo, clip, 8, layerwise)
+        ref.backward(g)
+        out.backward(g)
+        assert out.dtype == ref.dtype == torch.float32 and bits_equal(np_from(out), np_from(ref), "fp32"), (shape, layerwise)
+        assert bits_equal(np_from(xo.grad), np_from(xr.grad), dtype), (shape, layerwise)
+    EQ = TL.EagerQuant()
+    ours = QuantizeLinear(512, 256, w_bits=4, a_bits=8, weight_layerwise=True, act_layerwise=True).cuda().to(TD[dtype])
+    refm = EQ.QuantizeLinear(512, 256, w_bits=4, a_bits=8, weight_layerwise=True, act_layerwise=True).cuda().to(TD[dtype])
+    with torch.no_grad():
+        refm.weight.copy_(ours.weight)
+    xs = (torch.randn(8, 64, 512, device="cuda") * 1.5).to(TD[dtype])
+    res = []
+    for m in (ours, refm):
+        x = xs.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=TD[dtype]):
+            o = m(x)
+        o.float().square().mean().backward()
+        res.append((o.detach(), x.grad, m.weight.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)

@@ -71,6 +71,13 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
                 if off == 0:
                     ok(L.fq_ste_bwd_mask(gr.ptr, gx.ptr, rows, cols, -2.0, 2.0, bounds.ptr, mask.ptr, mb, code, st), "ste_bwd_mask")
                 ok(L.fq_asym_fwd_train(x.ptr, y.ptr, rows, cols, 4, code, 0, -0.5, 0.75, bounds.ptr, mask.ptr, mb, st), "asym_fwd_train", allow=(-8,))
+            if es == 2:   # the autocast arithmetic: bf16/fp16 in, fp32 (wide) or same-dtype (narrow) out
+                y32 = Guarded(n * 4, off * 2)
+                everything.append(y32)
+                ok(L.fq_sym_fwd_autocast(x.ptr, y32.ptr, rows, cols, 8, code, 1, -2.0, 2.0, bounds.ptr, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast wide")
+                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr if mb else None, mb, ws.ptr, wsb, st),
+                   "sym_fwd_autocast narrow", allow=(-8,))
+                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, None, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast narrow plain")
             sc = Guarded(rows * es)
             sc.payload().view(dtype).fill_(0.05)
             everything.append(sc)

@@ -439,6 +439,15 @@ def test_randomized_stress_all_paths(ops):
                 out.backward(gd)
                 assert bits_equal(np_from(out), yo, dtype), f"{tag} {mode} fwd"
                 assert bits_equal(np_from(xr.grad), want_g, dtype), f"{tag} {mode} grad: " + mismatch_report(np_from(xr.grad), want_g, dtype)
+            if kind == "sym" and dtype != "fp32":   # the same tensor under autocast: fp32 arithmetic, fp32 result
+                ya, _ = O.sym_fwd_autocast(x_np, r, c, bits, dtype, wide=True)
+                llm_qat_amd.set_backward_mode(["mask", "bounds", "plain"][trial % 3])
+                with torch.autocast("cuda", dtype=TD[dtype]):
+                    xr = xd.clone().requires_grad_(True)
+                    out = quant.apply(xr, torch.tensor([lo, hi]), bits, layerwise)
+                out.backward(gd.float())
+                assert out.dtype == torch.float32 and bits_equal(np_from(out).reshape(ya.shape), ya, "fp32"), f"{tag} autocast fwd"
+                assert bits_equal(np_from(xr.grad), want_g, dtype), f"{tag} autocast grad"
     finally:
         llm_qat_amd.set_backward_mode(prev)
 

@@ -99,3 +99,39 @@ def test_dropin_is_bit_identical_under_autocast():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for (n, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
         assert p.grad.dtype == torch.float32 and torch.equal(p.grad, q.grad), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reentrant", [True, False])
+def test_dropin_under_checkpointing_and_autocast(reentrant):
+    """run_train.sh's combination: bf16 weights, bf16 autocast, per-layer activation checkpointing (HF 4.30 used the
+    reentrant flavour).  Drop-in == eager chain, bit for bit, with the weight cache on as well."""
+    from torch.utils.checkpoint import checkpoint
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+
+    def step(model):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = model.model.embed_tokens(ids)
+            h.requires_grad_(True)
+            for layer in model.model.layers:
+                h = checkpoint(layer, h, use_reentrant=reentrant)
+            logits = model.lm_head(model.model.norm(h))
+            loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), ids[..., 1:].reshape(-1))
+        loss.backward()
+        return loss.detach(), [p.grad.clone() for p in model.parameters()]
+
+    ref = TL.load_deterministic(TL.TinyLlama(TL.EagerQuant(), w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+    ours = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+    l_ref, g_ref = step(ref)
+    for cache in (False, True):
+        llm_qat_amd.enable_weight_quant_cache(cache)
+        try:
+            l, g = step(ours)
+        finally:
+            llm_qat_amd.enable_weight_quant_cache(False)
+        assert torch.equal(l, l_ref), (cache, l.item(), l_ref.item())
+        for a, b, (n, _) in zip(g, g_ref, ours.named_parameters()):
+            assert torch.equal(a, b), (cache, n)

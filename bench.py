@@ -312,8 +312,9 @@ def parity_gate(wl, nrows=48):
     return res
 
 
-def gpu_eager(wl, iters=5):
-    """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd)."""
+def gpu_eager(wl, iters=5, autocast=False):
+    """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd).
+    autocast=True: inside torch.autocast("cuda", bf16), as LLM-QAT trains (fp32 intermediates behind the reciprocal)."""
     import torch
     from oracle import eager_chain as E
     clip = torch.tensor([-2.0, 2.0])
@@ -321,10 +322,11 @@ def gpu_eager(wl, iters=5):
 
     def one(k):
         s = wl.sets[k % wl.nsets]
-        E.sym_forward(s["w"], 4)
-        E.ste_backward(s["gw"], s["w"], clip)
-        E.sym_forward(s["a"], 8)
-        E.ste_backward(s["ga"], s["a"], clip)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            yw = E.sym_forward(s["w"], 4)
+            ya = E.sym_forward(s["a"], 8)
+        E.ste_backward(s["gw"].to(yw.dtype), s["w"], clip)
+        E.ste_backward(s["ga"].to(ya.dtype), s["a"], clip)
 
     one(0)
     torch.cuda.synchronize()
@@ -334,7 +336,8 @@ def gpu_eager(wl, iters=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {"value": round(2 * wl.n / dt / 1e9, 2), "unit": "Gelem/s", "ms_per_step": round(dt * 1e3, 3),
-            "what": "oracle/eager_chain.py (the reference's op chain) on the same tensors, same GPU"}
+            "what": "oracle/eager_chain.py (the reference's op chain) on the same tensors, same GPU"
+                    + (", inside torch.autocast(cuda, bf16) as LLM-QAT trains (fp32 intermediates, fp32 outputs)" if autocast else "")}
 
 
 def main():
@@ -431,6 +434,7 @@ def main():
                                 "what": "all four kernels of one step: 10 algorithmic B/elem / sum of launch times"}
         if world == 1:
             out["gpu_eager"] = gpu_eager(wl)
+            out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
                 out["cpu_baseline_c_port"] = cpu_c_port()

@@ -233,26 +233,13 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
 
 def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
-    not served by the STE-mask path (the caller then uses the general forward + x-based backward)."""
-    code = _prep(x, f"{kind}_quantize_train")
-    if x.numel() == 0 or not x.is_contiguous():
+    not served by the STE-mask path (the caller then uses the general forward + x-based backward).
+    Convenience form of train_forward() with the side buffer split into its two views."""
+    res = train_forward(kind, x, num_bits, layerwise, float(lo), float(hi))
+    if res is None:
         return None
-    rows, cols = rows_cols(tuple(x.shape), layerwise)
-    L = _lib.lib()
-    mbytes = L.fq_ste_mask_bytes(rows, cols, code)
-    if not mbytes:
-        return None
-    y = torch.empty_like(x)
-    bounds = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
-    mask = torch.empty(mbytes, dtype=torch.uint8, device=x.device)
-    fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
-    with _DeviceOf(x):
-        rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, float(lo), float(hi),
-                bounds.data_ptr(), mask.data_ptr(), mbytes, _stream(x))
-    if rc == _lib.ERR_UNSUPPORTED:
-        return None
-    _lib.check(rc, f"{kind}_quantize_train")
-    return y, bounds, mask
+    y, side, rows, _ = res
+    return y, side[: rows * 8].view(torch.float32).view(rows, 2), side[rows * 8:]
 
 
 def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols):

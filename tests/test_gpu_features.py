@@ -108,7 +108,7 @@ def test_shared_activation_quant_is_transparent(pkg, dtype):
             x = xs.clone().requires_grad_(True)
             for m in mods:
                 m.zero_grad(set_to_none=True)
-            with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
+            with Counter(pkg.ops, ["train_forward", "sym_quantize"]) as c:
                 loss = qkv_loss(mods, x)
             loss.backward()
             res[share] = (loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n)
@@ -125,7 +125,7 @@ def test_shared_activation_respects_inplace_and_identity(pkg):
     from llm_qat_amd.utils_quant import QuantizeLinear
     m1, m2 = (QuantizeLinear(256, 64, w_bits=32, a_bits=8).cuda() for _ in range(2))
     x = torch.randn(4, 256, device="cuda")
-    with torch.no_grad(), Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize"]) as c:
+    with torch.no_grad(), Counter(pkg.ops, ["train_forward", "sym_quantize"]) as c:
         m1(x)
         m2(x)                      # same tensor, same version -> shared
         assert c.n == 1
@@ -179,7 +179,7 @@ def _weight_quant_cache_body(pkg):
         try:
             net.zero_grad(set_to_none=True)
             x = xs.clone().requires_grad_(True)
-            with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize", "sym_forward_autocast"]) as c:
+            with Counter(pkg.ops, ["train_forward", "sym_quantize", "sym_forward_autocast"]) as c:
                 out = checkpoint(net, x, use_reentrant=False)
                 out.float().square().mean().backward()
             res[cache] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()], c.n)
@@ -194,7 +194,7 @@ def _weight_quant_cache_body(pkg):
     pkg.enable_weight_quant_cache(True, persistent=True)
     try:
         net.zero_grad(set_to_none=True)
-        with Counter(pkg.ops, ["train_forward", "quantize_train", "sym_quantize", "sym_forward_autocast"]) as c:
+        with Counter(pkg.ops, ["train_forward", "sym_quantize", "sym_forward_autocast"]) as c:
             for micro in range(3):
                 checkpoint(net, xs.clone().requires_grad_(True), use_reentrant=False).float().square().mean().backward()
         assert c.n == 2 + 3 * 2 * 2                                     # 2 weights once + activations every pass

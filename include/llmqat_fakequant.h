@@ -162,6 +162,25 @@ int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int 
                         void* stream);
 
 /*
+ * QuantizeLinear.forward (models/utils_quant.py:195-248) fake-quantizes its weight [out, in] (w_bits, per output
+ * channel) and its input [tokens, in] (a_bits, per token) at the same moment, and both reduce over `in`: the same row
+ * length, hence the same launch shape.  These entry points do the two tensors in ONE launch (each launch carries
+ * ~2.8 us of fixed cost on MI355X), with results bit-identical to two separate calls.
+ *   tensor 0 / tensor 1  same dtype and `cols`; own rows, bit width, outputs.  row_bounds / mask are optional per
+ *                        tensor (training mode; a mask needs its row_bounds).
+ *   autocast             0: the arithmetic of fq_sym_fwd_train;  1: of fq_sym_fwd_autocast with wide_out = 0
+ * Only the register-resident kernels serve pairs: FQ_ERR_UNSUPPORTED for misaligned rows or rows longer than 8192
+ * 16-byte vectors (fall back to two calls).
+ */
+int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* row_bounds0, void* mask0, size_t mask_bytes0,
+                    const void* x1, void* y1, int64_t rows1, int bits1, float* row_bounds1, void* mask1, size_t mask_bytes1,
+                    int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream);
+/* STE backward of both tensors of a pair in one launch (F.linear's backward produces both gradients together). */
+int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
+                         const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
+                         int64_t cols, float lo, float hi, int dtype, void* stream);
+
+/*
  * QuantizeLinear's 1- and 2-bit weight branches -- models/utils_quant.py:202-242, elementwise part:
  *   w_bits==1 : q = sc * sign(w / sc)
  *   w_bits==2 : q = sc * (round(clamp(w / sc, -0.99, 0.99) * 2 - 0.5) + 0.5) / 2

@@ -95,7 +95,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, sem);
-    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f};
+    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, nullptr, nullptr, nullptr, nullptr, 0.f};
     if (mk) {
         if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
         const int64_t mrw = mask_row_words(cols, esize_of(dtype));
@@ -187,7 +187,7 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, FQ_SEM_DEVICE_EAGER);
-    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f};
+    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, nullptr, nullptr, nullptr, nullptr, 0.f};
     if (mask_out) {
         if (!row_bounds_out) return fail(FQ_ERR_NULL, "a mask needs row_bounds_out too");
         const int64_t mrw = mask_row_words(cols, 2);
@@ -201,6 +201,50 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
     hipStream_t st = (hipStream_t)stream;
     return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide_out != 0, a, workspace, workspace_bytes, st)
                                   : launch_sym_autocast<F16>(wide_out != 0, a, workspace, workspace_bytes, st);
+}
+
+FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* row_bounds0, void* mask0, size_t mask_bytes0,
+                           const void* x1, void* y1, int64_t rows1, int bits1, float* row_bounds1, void* mask1, size_t mask_bytes1,
+                           int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (bits0 < 2 || bits0 > 31 || bits1 < 2 || bits1 > 31) return fail(FQ_ERR_BITS, "num_bits outside [2, 31]");
+    if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
+    if (autocast && dtype == FQ_DTYPE_F32) return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
+    if (rows0 <= 0 || rows1 <= 0 || cols <= 0) return fail(FQ_ERR_SHAPE, "pair launch needs two non-empty tensors");
+    if (!x0 || !y0 || !x1 || !y1) return fail(FQ_ERR_NULL, "pair launch: x / y of both tensors required");
+    if ((mask0 && !row_bounds0) || (mask1 && !row_bounds1)) return fail(FQ_ERR_NULL, "a mask needs its row_bounds too");
+    const int64_t mrw = mask_row_words(cols, esize_of(dtype));
+    if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the register kernels (see fq_ste_mask_bytes)");
+    if ((mask0 && mask_bytes0 < (size_t)rows0 * mrw * 8) || (mask1 && mask_bytes1 < (size_t)rows1 * mrw * 8))
+        return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
+    const Consts c0 = make_consts(bits0, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem), c1 = make_consts(bits1, dtype, sem);
+    RowArgs a{x0, y0, nullptr, nullptr, row_bounds0, rows0 + rows1, cols, c0.sym, c0.asym, (uint64_t*)mask0, mrw, host_rb(lo, dtype), host_rb(hi, dtype),
+              rows0, x1, y1, row_bounds1, (uint64_t*)mask1, c1.sym.qmax};
+    hipStream_t st = (hipStream_t)stream;
+    if (autocast) return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(false, a, nullptr, 0, st) : launch_sym_autocast<F16>(false, a, nullptr, 0, st);
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_rowwise<F32>(false, true, a, nullptr, 0, st);
+        case FQ_DTYPE_F16: return launch_rowwise<F16>(false, true, a, nullptr, 0, st);
+        default: return launch_rowwise<BF16>(false, true, a, nullptr, 0, st);
+    }
+}
+
+FQ_API int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
+                                const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
+                                int64_t cols, float lo, float hi, int dtype, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (rows0 <= 0 || rows1 <= 0 || cols <= 0) return fail(FQ_ERR_SHAPE, "pair launch needs two non-empty tensors");
+    if (!g0 || !gx0 || !g1 || !gx1 || !row_bounds0 || !row_bounds1 || !mask0 || !mask1) return fail(FQ_ERR_NULL, "pair launch: all buffers required");
+    if (!mask_row_words(cols, esize_of(dtype))) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path");
+    lo = host_rb(lo, dtype);
+    hi = host_rb(hi, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const SteSecond sec{rows0, g1, gx1, row_bounds1, (const uint64_t*)mask1};
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_ste_mask<F32>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
+        case FQ_DTYPE_F16: return launch_ste_mask<F16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
+        default: return launch_ste_mask<BF16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
+    }
 }
 
 FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,

@@ -72,9 +72,13 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
     } else {
         constexpr int EPV = 8;
-        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0);
+        const bool pair = a.x1 != nullptr;
+        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && (!pair || (aligned16(a.x1) && aligned16(a.y1)));
         const int64_t nvec = a.cols / EPV;
-        const int64_t bytes = a.rows * a.cols * T::ESIZE;
+        const int64_t big_rows = pair ? (a.rows0 > a.rows - a.rows0 ? a.rows0 : a.rows - a.rows0) : a.rows;
+        const int64_t bytes = big_rows * a.cols * T::ESIZE;
+        if (pair && (AC == 2 || !(vec_ok && nvec <= REG_MAX_VEC)))
+            return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
         if constexpr (AC == 2) {
             // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced; no STE mask on this path
@@ -131,11 +135,14 @@ template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
-    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0);
+    const bool pair = a.x1 != nullptr;  // two tensors in one launch: register kernels only
+    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && (!pair || (aligned16(a.x1) && aligned16(a.y1)));
     const int64_t nvec = a.cols / EPV;
-    const int64_t bytes = a.rows * a.cols * T::ESIZE;
+    const int64_t big_rows = pair ? (a.rows0 > a.rows - a.rows0 ? a.rows0 : a.rows - a.rows0) : a.rows;
+    const int64_t bytes = big_rows * a.cols * T::ESIZE;  // cache policy follows the larger tensor
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
     bool two_pass = false, two_pass_vec = false;
+    if (pair && !(vec_ok && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
     if (vec_ok && nvec <= REG_MAX_VEC) {
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
         // the diagnostic outputs (bin indices, scales) live in their own instantiation so the product
@@ -239,24 +246,27 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
 
 template <int DT>
 int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
-                    hipStream_t st) {
+                    hipStream_t st, const SteSecond* second) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw || !(aligned16(g) && aligned16(gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape/alignment not served");
+    if (second && !(aligned16(second->g) && aligned16(second->gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served");
+    const SteSecond sec = second ? *second : SteSecond{rows, nullptr, nullptr, nullptr, nullptr};
     const int64_t nvec_row = cols / EPV;
     const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
     int cv = (int)((nvec_row + chunks - 1) / chunks);
     cv = (cv + 63) / 64 * 64;  // every wave covers exactly one 64-vector mask group per slot
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
     if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-    const int64_t bytes = rows * cols * T::ESIZE;
+    const int64_t big_rows = second ? (sec.rows0 > rows - sec.rows0 ? sec.rows0 : rows - sec.rows0) : rows;
+    const int64_t bytes = big_rows * cols * T::ESIZE;
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
-#define S(V)                                                                                                                                    \
-    case V:                                                                                                                                     \
-        if (ntl) FQ_LAUNCH((ste_mask_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);        \
-        else if (nts) FQ_LAUNCH((ste_mask_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);  \
-        else FQ_LAUNCH((ste_mask_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi);          \
+#define S(V)                                                                                                                                         \
+    case V:                                                                                                                                          \
+        if (ntl) FQ_LAUNCH((ste_mask_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);        \
+        else if (nts) FQ_LAUNCH((ste_mask_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);  \
+        else FQ_LAUNCH((ste_mask_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);          \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -291,7 +301,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
-    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t); \
+    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteSecond*); \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 
 }  // namespace fq

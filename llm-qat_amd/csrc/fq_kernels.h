@@ -33,6 +33,16 @@ struct RowArgs {
     uint64_t* mask;
     int64_t mask_row_words;
     float lo, hi;
+    // optional SECOND tensor of the same launch (register-resident Sym kernels only): same dtype and cols (so the same
+    // launch shape), its own rows / bit width / outputs.  QuantizeLinear needs its weight [out, in] and its input
+    // [tokens, in] fake-quantized at the same moment and both reduce over `in`: one launch instead of two saves the
+    // ~2.8 us launch boundary.  Rows [0, rows0) belong to the first tensor, [rows0, rows) to the second.
+    int64_t rows0;
+    const void* x1;
+    void* y1;
+    float* bounds1;
+    uint64_t* mask1;
+    float qmax1;
 };
 
 // STE bit mask layout (private to the forward/backward kernel pair, independent of launch shape):
@@ -96,9 +106,23 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         row = blockIdx.x;
         t = threadIdx.x;
     }
+    // which tensor of the launch this row belongs to (wave-uniform)
+    const void* xb = a.x;
+    void* yb = a.y;
+    float* bnd = a.bounds;
+    uint64_t* msk = a.mask;
+    SymConst symk = a.sym;
+    if (row >= a.rows0) {
+        row -= a.rows0;
+        xb = a.x1;
+        yb = a.y1;
+        bnd = a.bounds1;
+        msk = a.mask1;
+        symk.qmax = a.qmax1;
+    }
     const int nvec = (int)(a.cols / EPV);
-    const uint4* __restrict__ xr = (const uint4*)((const char*)a.x + row * a.cols * T::ESIZE);
-    uint4* __restrict__ yr = (uint4*)((char*)a.y + row * a.cols * T::ESIZE);
+    const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row * a.cols * T::ESIZE);
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row * a.cols * T::ESIZE);
 
     uint4 r[VPT];
 #pragma unroll
@@ -122,15 +146,15 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         }
         const uint32_t mbits = block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]);
         const float m = as_f(mbits);
-        if constexpr (AC == 0) sr = sym_row<DT>(m, a.sym);
-        else sr = sym_row_autocast<DT>(m, a.sym.qmax);
+        if constexpr (AC == 0) sr = sym_row<DT>(m, symk);
+        else sr = sym_row_autocast<DT>(m, symk.qmax);
         ub = m;
         lb = -m;
         if (t == 0) {
             if (DBG && a.scale) a.scale[row] = sr.s;
-            if (a.bounds) {
-                a.bounds[2 * row] = m;
-                a.bounds[2 * row + 1] = -m;
+            if (bnd) {
+                bnd[2 * row] = m;
+                bnd[2 * row + 1] = -m;
             }
         }
     } else {
@@ -160,17 +184,17 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
                 a.scale[2 * row] = ar.al;
                 a.scale[2 * row + 1] = ar.mn;
             }
-            if (a.bounds) {
-                a.bounds[2 * row] = mx;
-                a.bounds[2 * row + 1] = mn;
+            if (bnd) {
+                bnd[2 * row] = mx;
+                bnd[2 * row + 1] = mn;
             }
         }
     }
 
     // Elementwise pass.  Rows that can actually be clipped also emit the STE bit mask for the backward.
-    const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
+    const bool want_mask = msk && !((ub < a.hi) && (lb > a.lo));  // wave-uniform
     const bool sym_clip = a.lo == -a.hi;
-    uint64_t* mrow = a.mask + row * a.mask_row_words;
+    uint64_t* mrow = msk + row * a.mask_row_words;
     int32_t* idxr = (DBG && a.idx) ? a.idx + row * a.cols : nullptr;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[e] = sym_elem_autocast(f[e], sr);
             if constexpr (AC == 2) {  // fp32 result: two 16-byte stores per input vector
-                uint4* y32 = (uint4*)((char*)a.y + row * a.cols * 4);
+                uint4* y32 = (uint4*)((char*)yb + row * a.cols * 4);
                 if (v < nvec) {
                     st16<NTS>(&y32[2 * v], make_uint4(as_u(f[0]), as_u(f[1]), as_u(f[2]), as_u(f[3])));
                     st16<NTS>(&y32[2 * v + 1], make_uint4(as_u(f[4]), as_u(f[5]), as_u(f[6]), as_u(f[7])));
@@ -738,14 +762,29 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
 // clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
 // every wave covers exactly one mask group per slot.
+struct SteSecond {  // optional second tensor of a mask-backward launch (same dtype and cols; see RowArgs)
+    int64_t rows0;
+    const void* g;
+    void* gx;
+    const float* bounds;
+    const uint64_t* mask;
+};
+
 template <int DT, int VPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nvec_row,
                                                                int64_t chunks, int cv, const float* __restrict__ bounds,
                                                                const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
-                                                               float hi) {
+                                                               float hi, SteSecond second) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
-    const int64_t row = blockIdx.x / chunks;
+    int64_t row = blockIdx.x / chunks;
+    if (row >= second.rows0) {  // block-uniform
+        row -= second.rows0;
+        g = second.g;
+        gx = second.gx;
+        bounds = second.bounds;
+        mask = second.mask;
+    }
     const int64_t vs = (blockIdx.x % chunks) * cv;
     const int64_t off = row * nvec_row + vs;
     const uint4* gr = (const uint4*)g + off;

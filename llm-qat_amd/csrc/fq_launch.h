@@ -38,7 +38,7 @@ template <int DT> FQ_HIDDEN int launch_sym_autocast(bool wide, RowArgs a, void* 
 template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
 template <int DT>
 FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                              const uint64_t* mask, hipStream_t st);
+                              const uint64_t* mask, hipStream_t st, const SteSecond* second = nullptr);
 template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);

@@ -231,6 +231,56 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     return y, side, rows, cols, got
 
 
+def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x):
+    """QuantizeLinear's two operands in ONE launch (fq_sym_fwd_pair): weight [out, in] per output channel and input
+    [..., in] per token share the row length.  -> (wq, xq, side_w, side_x, rows_w, rows_x, cols) or None when the pair
+    is not served (different dtypes / devices, misaligned, non-contiguous, rows too long): use two calls then.
+    side_* (row bounds + STE mask, as in train_forward) is produced only for the operands that need a gradient."""
+    if w.dtype != x.dtype or w.device != x.device or not (w.is_cuda and w.is_contiguous() and x.is_contiguous()):
+        return None
+    code = _DTYPES.get(w.dtype)
+    if code is None or w.dim() != 2 or x.dim() < 1 or x.dim() > 3 or x.shape[-1] != w.shape[1] or x.numel() == 0 or w.numel() == 0:
+        return None
+    cols = w.shape[1]
+    rows_w, rows_x = w.shape[0], x.numel() // cols
+    mw, mx = _mask_bytes(rows_w, cols, code), _mask_bytes(rows_x, cols, code)
+    if not mw or not mx:
+        return None
+    ac = autocast_active(w)
+    L = _lib.lib()
+    wq, xq = torch.empty_like(w), torch.empty_like(x)
+    side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device) if need_w else None
+    side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device) if need_x else None
+    pw, px = (side_w.data_ptr() if need_w else None), (side_x.data_ptr() if need_x else None)
+    with _DeviceOf(w):
+        rc = L.fq_sym_fwd_pair(w.data_ptr(), wq.data_ptr(), rows_w, int(w_bits), pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
+                               x.data_ptr(), xq.data_ptr(), rows_x, int(a_bits), px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
+                               cols, code, _semantics, 1 if ac else 0, float(lo), float(hi), _stream(w))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "quantize_linear_pair")
+    return wq, xq, side_w, side_x, rows_w, rows_x, cols
+
+
+def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi):
+    """STE backward of both operands in one launch; either gradient may be None (then only the other is computed)."""
+    if gw is None or gx is None:
+        g, side, rows = (gw, side_w, rows_w) if gx is None else (gx, side_x, rows_x)
+        return (train_backward(g, side, rows, cols, lo, hi), None) if gx is None else (None, train_backward(g, side, rows, cols, lo, hi))
+    code = _DTYPES.get(gw.dtype)
+    gw = gw if gw.is_contiguous() else gw.contiguous()
+    gx = gx if gx.is_contiguous() else gx.contiguous()
+    ow, ox = torch.empty_like(gw), torch.empty_like(gx)
+    pw, px = side_w.data_ptr(), side_x.data_ptr()
+    with _DeviceOf(gw):
+        rc = _lib.lib().fq_ste_bwd_mask_pair(gw.data_ptr(), ow.data_ptr(), rows_w, pw, pw + rows_w * 8,
+                                             gx.data_ptr(), ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, float(lo), float(hi), code, _stream(gw))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return train_backward(gw, side_w, rows_w, cols, lo, hi), train_backward(gx, side_x, rows_x, cols, lo, hi)
+    _lib.check(rc, "quantize_linear_pair_backward")
+    return ow, ox
+
+
 def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
     not served by the STE-mask path (the caller then uses the general forward + x-based backward).

@@ -193,21 +193,24 @@ def enable_weight_quant_cache(flag=True, persistent=False):
     _WEIGHT_CACHE_PERSISTENT = bool(flag) and bool(persistent)
 
 
-def _shared_activation(quantizer, x, num_bits, layerwise):
-    if quantizer is SymQuantizer:
-        quantizer = _SymQuantizerOperand
-    if not _SHARE_ACT:
-        return quantizer.apply(x, _CLIP, num_bits, layerwise)
+def _act_key(quantizer, x, num_bits, layerwise):
+    return (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(x))
+
+
+def _act_lookup(key, x):
     cache = getattr(_tls, "act", None)
-    if cache is None:
-        cache = _tls.act = {}
-    key = (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(x))
-    ent = cache.get(key)
+    ent = cache.get(key) if cache else None
     if ent is not None:
         rin, ver_in, y, ver_out, epoch = ent
         if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0]:
             return y
-    y = quantizer.apply(x, _CLIP, num_bits, layerwise)
+    return None
+
+
+def _act_store(key, x, y):
+    cache = getattr(_tls, "act", None)
+    if cache is None:
+        cache = _tls.act = {}
 
     def _drop(ref, cache=cache, key=key):  # the input died: nobody can ask for this result again
         ent = cache.get(key)
@@ -215,7 +218,52 @@ def _shared_activation(quantizer, x, num_bits, layerwise):
             del cache[key]
 
     cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0])
+
+
+def _shared_activation(quantizer, x, num_bits, layerwise):
+    if quantizer is SymQuantizer:
+        quantizer = _SymQuantizerOperand
+    if not _SHARE_ACT:
+        return quantizer.apply(x, _CLIP, num_bits, layerwise)
+    key = _act_key(quantizer, x, num_bits, layerwise)
+    y = _act_lookup(key, x)
+    if y is None:
+        y = quantizer.apply(x, _CLIP, num_bits, layerwise)
+        _act_store(key, x, y)
     return y
+
+
+# 3. QuantizeLinear needs its weight [out, in] and its input [tokens, in] fake-quantized at the same moment, and both
+#    reduce over `in` (same row length = same launch shape): one two-tensor launch forward, one backward (F.linear's
+#    backward produces both gradients together), instead of two each -- a launch carries ~2.8 us of fixed cost.
+_PAIR = os.environ.get("LLMQAT_AMD_PAIR_OPERANDS", "1") != "0"
+
+
+def pair_operands(flag=True):
+    global _PAIR
+    _PAIR = bool(flag)
+
+
+class _PairNode(torch.autograd.Function):
+    """Autograd node over the results of one ops.pair_forward launch (weight and input of a QuantizeLinear)."""
+
+    @staticmethod
+    def forward(ctx, weight, input, res):
+        wq, xq, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
+        ctx.dtype = weight.dtype
+        ctx.set_materialize_grads(False)
+        return wq.view_as(wq), xq.view_as(xq)
+
+    @staticmethod
+    def backward(ctx, gw, gx):
+        _bwd_epoch[0] += 1
+        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gw = gw.to(ctx.dtype) if (need_w and gw is not None and gw.dtype != ctx.dtype) else (gw if need_w else None)
+        gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
+        if gw is None and gx is None:
+            return None, None, None
+        ow, ox = ops.pair_backward(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, -2.0, 2.0)
+        return ow, ox, None
 
 
 class _ReuseQuantizedWeight(torch.autograd.Function):
@@ -298,8 +346,33 @@ class QuantizeLinear(nn.Linear):
             return _ReuseQuantizedWeight.apply(w, cached, _CLIP)  # launches nothing; backward = the ordinary STE
         return cached[0]
 
+    def _pair_forward(self, input_):
+        """weight and input in one launch; None when the pair is not applicable (then the ordinary two calls run)"""
+        if not (_PAIR and _BACKWARD_MODE == "mask" and not _WEIGHT_CACHE and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
+            return None
+        if self.act_quantizer is not SymQuantizer or self.act_layerwise or self.weight_layerwise:
+            return None
+        key = _act_key(_SymQuantizerOperand, input_, self.a_bits, False) if _SHARE_ACT else None
+        if key is not None and _act_lookup(key, input_) is not None:
+            return None  # a sibling projection already quantized this activation: only the weight is left to do
+        grad = torch.is_grad_enabled()
+        res = ops.pair_forward(self.weight, input_, self.w_bits, self.a_bits, -2.0, 2.0,
+                               grad and self.weight.requires_grad, grad and input_.requires_grad)
+        if res is None:
+            return None
+        if grad and (self.weight.requires_grad or input_.requires_grad):
+            wq, xq = _PairNode.apply(self.weight, input_, res)
+        else:
+            wq, xq = res[0], res[1]
+        if key is not None:
+            _act_store(key, input_, xq)
+        return wq, xq
+
     def forward(self, input_):
         assert len(self.weight.size()) == 2
+        pair = self._pair_forward(input_)
+        if pair is not None:
+            return nn.functional.linear(pair[1], pair[0])
         if self.w_bits >= 32:
             weight = self.weight
         elif self.w_bits >= 3:

@@ -24,6 +24,14 @@ def pkg():
     return llm_qat_amd
 
 
+@pytest.fixture
+def no_pairing(pkg):
+    """launch-count assertions below are written for the unpaired data flow (weight and input in separate launches)"""
+    pkg.pair_operands(False)
+    yield
+    pkg.pair_operands(True)
+
+
 # ------------------------------------------------------------------------------------------ W1 / W2
 def test_low_bit_weight_golden(pkg):
     G = golden("w12.npz")
@@ -96,7 +104,7 @@ def qkv_loss(mods, x):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_shared_activation_quant_is_transparent(pkg, dtype):
+def test_shared_activation_quant_is_transparent(pkg, dtype, no_pairing):
     from llm_qat_amd.utils_quant import QuantizeLinear
     torch.manual_seed(0)
     mods = [QuantizeLinear(512, 384, w_bits=4, a_bits=8).cuda().to(dtype) for _ in range(3)]
@@ -121,7 +129,7 @@ def test_shared_activation_quant_is_transparent(pkg, dtype):
     assert res[False][3] == 6 and res[True][3] == 4                  # 3 weights + 3 activations -> 3 weights + 1 activation
 
 
-def test_shared_activation_respects_inplace_and_identity(pkg):
+def test_shared_activation_respects_inplace_and_identity(pkg, no_pairing):
     from llm_qat_amd.utils_quant import QuantizeLinear
     m1, m2 = (QuantizeLinear(256, 64, w_bits=32, a_bits=8).cuda() for _ in range(2))
     x = torch.randn(4, 256, device="cuda")
@@ -156,7 +164,7 @@ def test_shared_activation_not_reused_across_training_steps(pkg):
 
 
 @pytest.mark.parametrize("autocast", [False, True])
-def test_weight_quant_cache_with_checkpoint(pkg, autocast):
+def test_weight_quant_cache_with_checkpoint(pkg, autocast, no_pairing):
     from llm_qat_amd.utils_quant import QuantizeLinear
     torch.manual_seed(1)
     ctx = torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast)
@@ -352,3 +360,45 @@ def test_mask_mode_backward_needs_no_input_storage(pkg):
     flat.untyped_storage().resize_(0)                                   # "reshard": the weight's memory is released
     (gw,) = torch.autograd.grad(y, w, g)
     assert torch.equal(gw, torch.where(ref_mask, torch.zeros_like(g), g))
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_paired_operand_launch_is_transparent(pkg, dtype, autocast):
+    """QuantizeLinear quantizes weight and input in ONE launch (and their gradients in one): outputs and gradients are
+    bit-identical to the two-launch flow; q/k/v siblings still share the activation (the first pairs, the others do only
+    their weight)."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(0)
+    mods = [QuantizeLinear(1024, 768, w_bits=4, a_bits=8).cuda().to(dtype) for _ in range(3)]
+    with torch.no_grad():
+        mods[0].weight[3, 5] = 2.5
+    xs = (torch.randn(2, 64, 1024, device="cuda") * 1.5).to(dtype)
+    res = {}
+    for pair in (True, False):
+        pkg.pair_operands(pair)
+        try:
+            x = xs.clone().requires_grad_(True)
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            with Counter(pkg.ops, ["pair_forward", "pair_backward", "train_forward", "train_backward", "sym_forward_autocast"]) as c:
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                    loss = qkv_loss(mods, x)
+                loss.backward()
+            res[pair] = (loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n)
+        finally:
+            pkg.pair_operands(True)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[True][2][0][3, 5] == 0
+    # unpaired: 3 weights + 1 shared activation forward, 4 backward = 8 calls; paired: (1 pair + 2 weights) + (1 pair + 2) = 6
+    assert res[False][3] == 8 and res[True][3] == 6, (res[False][3], res[True][3])
+    # eval / no-grad
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            a = mods[0](xs)
+            pkg.pair_operands(False)
+            b = mods[0](xs)
+            pkg.pair_operands(True)
+    assert torch.equal(a, b)

@@ -173,7 +173,7 @@ __global__ void fill_bf16(uint16_t* p, int64_t n, uint32_t seed, float scale) {
 template <int TPR, int VPT, bool FAST, bool NTL, bool NTS>
 static void launch_sym(const void* x, void* y, float* bounds, int64_t rows, int64_t cols, int bits) {
     RowArgs a{};
-    a.x = x; a.y = y; a.idx = nullptr; a.scale = nullptr; a.bounds = bounds; a.rows = rows; a.cols = cols;
+    a.x = x; a.y = y; a.idx = nullptr; a.scale = nullptr; a.bounds = bounds; a.rows = rows; a.rows0 = rows; a.cols = cols;
     a.sym.qmax = (float)((1 << (bits - 1)) - 1);
     a.sym.c6 = 9.98377799987793e-07f;
     const int64_t grid = TPR == 64 ? (rows + 3) / 4 : rows;

@@ -153,9 +153,31 @@ class Workload:
         if rc:
             self._lib.check(rc, "fq_ste_bwd")
 
+    # The product's default data flow for a QuantizeLinear: its weight [out, in] (W4) and its input [tokens, in] (A8)
+    # in ONE launch forward, their STE gradients in one launch backward (fq_sym_fwd_pair / fq_ste_bwd_mask_pair).
+    def fwd_pair(self, s):
+        rc = self.L.fq_sym_fwd_pair(s["w"].data_ptr(), s["yw"].data_ptr(), self.rows, 4, s["bw"].data_ptr(), s["mw"].data_ptr(), self.mask_bytes,
+                                    s["a"].data_ptr(), s["ya"].data_ptr(), self.rows, 8, s["ba"].data_ptr(), s["ma"].data_ptr(), self.mask_bytes,
+                                    self.cols, self._lib.DTYPE_BF16, self._lib.SEM_CPU_EAGER, 0, -2.0, 2.0, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_sym_fwd_pair")
+
+    def bwd_pair(self, s):
+        rc = self.L.fq_ste_bwd_mask_pair(s["gw"].data_ptr(), s["gxw"].data_ptr(), self.rows, s["bw"].data_ptr(), s["mw"].data_ptr(),
+                                         s["ga"].data_ptr(), s["gxa"].data_ptr(), self.rows, s["ba"].data_ptr(), s["ma"].data_ptr(),
+                                         self.cols, -2.0, 2.0, self._lib.DTYPE_BF16, self.stream)
+        if rc:
+            self._lib.check(rc, "fq_ste_bwd_mask_pair")
+
     def step(self, i):
         # forward on set i, backward on the set whose forward ran two steps ago: between the forward
         # and the backward of one tensor > 1.4 GB of other traffic passes, as in a real training step
+        sf = self.sets[i % self.nsets]
+        sb = self.sets[(i + self.nsets - 2) % self.nsets]
+        self.fwd_pair(sf)
+        self.bwd_pair(sb)
+
+    def step_unpaired(self, i):
         sf = self.sets[i % self.nsets]
         sb = self.sets[(i + self.nsets - 2) % self.nsets]
         self.fwd(sf, "w")
@@ -406,7 +428,8 @@ def main():
                                "[4096,11008], bf16, clip [-2,2] (LLaMA-7B W4-A8 down_proj shapes, configs[1])",
                    "elements_per_step": elems_step, "buffer_sets": wl.nsets, "parallelism": "replicas" if world > 1 else "1gpu",
                    "semantics": "cpu_eager",
-                   "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x)"},
+                   "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x)",
+                   "launches_per_step": "2 (weight + input of a QuantizeLinear share one forward and one backward launch)"},
         "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
     }
 
@@ -420,6 +443,16 @@ def main():
             "ste_bwd_a8": (lambda s: wl.bwd(s, "a"), nb * BWD_BYTES_PER_ELEM),
             "ste_bwd_w4": (lambda s: wl.bwd(s, "w"), nb * BWD_BYTES_PER_ELEM),
         }
+        pk = {
+            "sym_fwd_pair_w4a8": (lambda s: wl.fwd_pair(s), 2 * nb * FWD_BYTES_PER_ELEM),
+            "ste_bwd_pair_w4a8": (lambda s: wl.bwd_pair(s), 2 * nb * BWD_BYTES_PER_ELEM),
+        }
+
+        def pair_traffic(k):
+            parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8"), "ste_bwd_pair_w4a8": ("ste_bwd_w4", "ste_bwd_a8")}[k]
+            return sum(traffic[p] for p in parts) if all(p in traffic for p in parts) else None
+
+        out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it), pair_traffic(k)) for k, (fn, b) in pk.items()]
         kernels = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ks.items()]
         out["kernels"] = kernels
         # the reference's data flow on the same kernels' siblings: forward without mask/bounds, backward re-reading x
@@ -434,26 +467,21 @@ def main():
             "sym_fwd_a8_autocast_fp32_out": (lambda s: wl.fwd_autocast(s, "a", True), nb * 6),  # read 2 + write 4 B/elem
         }
         out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ac.items()]
-        # `roofline`: the forward kernel (row_reg_kernel: reduce -> scale -> round -> dequant), its W4 and A8 launches
-        # pooled.  The four launches of a step take the same time within noise (30-32 us), so "longest" would flip
-        # from run to run; the forward is the kernel that moves exactly the algorithmic bytes, so its fraction is a real
-        # byte rate (the mask backward moves fewer bytes than its 6 B/elem accounting: see `kernels`, frac > 1).
-        fw = [e for e in kernels if e["kernel"].startswith("sym_fwd")]
-        fus = sum(e["us_per_launch"] for e in fw)
-        fbytes = sum(e["algorithmic_bytes_per_launch"] for e in fw)
-        ftraffic = sum(e["traffic"] for e in fw) if all(e.get("traffic") for e in fw) else None
-        out["roofline"] = {"bound": "hbm", "achieved": round(fbytes / (fus * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(fbytes / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": None if ftraffic is None else ftraffic / len(fw),
-                           "kernel": "row_reg_kernel (Sym forward; W4 and A8 launches pooled, per-launch averages)",
-                           "us_per_launch": round(fus / len(fw), 2)}
-        if ftraffic:
-            out["roofline"]["traffic_gbs"] = round(ftraffic / (fus * 1e-6) / 1e9, 1)
-            out["roofline"]["traffic_frac"] = round(ftraffic / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        tot_us = sum(e["us_per_launch"] for e in kernels)
+        # `roofline`: the forward launch of the step (row_reg_kernel over the W4 weight and the A8 input: reduce -> scale ->
+        # round -> dequant).  It moves exactly its algorithmic bytes, so its fraction is a real byte rate; the mask backward
+        # moves fewer bytes than its 6 B/elem accounting (see `kernels_step`, frac > 1).
+        fwp = out["kernels_step"][0]
+        out["roofline"] = {k: fwp[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch") if k in fwp}
+        out["roofline"]["kernel"] = "row_reg_kernel (Sym forward of the step: W4 weight + A8 input in one launch)"
+        for k in ("traffic_gbs", "traffic_frac"):
+            if k in fwp:
+                out["roofline"][k] = fwp[k]
+        tot_us = sum(e["us_per_launch"] for e in out["kernels_step"])
         out["roofline_step"] = {"bound": "hbm", "achieved": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                "what": "all four kernels of one step: 10 algorithmic B/elem / sum of launch times"}
+                                "what": "both launches of one step: 10 algorithmic B/elem / sum of launch times"}
+        out["unpaired_step"] = {"ms_per_step": round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
+                                "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2)"}
         if world == 1:
             out["gpu_eager"] = gpu_eager(wl)
             out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)

@@ -449,6 +449,8 @@ def main():
         }
 
         def pair_traffic(k):
+            if k in traffic:
+                return traffic[k]
             parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8"), "ste_bwd_pair_w4a8": ("ste_bwd_w4", "ste_bwd_a8")}[k]
             return sum(traffic[p] for p in parts) if all(p in traffic for p in parts) else None
 

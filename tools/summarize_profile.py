@@ -25,12 +25,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOWN = 4096 * 11008 * 2
 
 
-def counters(path):
+def counters(path, by_grid=False):
+    """counter values per kernel; by_grid: key = (kernel name, grid size) so that paired (two-tensor) launches of the
+    same kernel are kept apart from single-tensor ones"""
     d = collections.defaultdict(list)
     for f in glob.glob(os.path.join(path, "runc", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            d[(r["Kernel_Name"], int(r["Grid_Size"])) if by_grid else r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return d
+
+
+def ac_flag(name):
+    """last template argument of row_reg_kernel (AC: 0 = plain arithmetic, 1 = autocast)"""
+    import re
+    m = re.search(r"row_reg_kernel<[^>]*,\s*(\d)>", name)
+    return int(m.group(1)) if m else None
 
 
 def short(name):
@@ -60,6 +69,18 @@ def main():
         if "fq::" in r["Kernel_Name"]:
             dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
+    # 1b. the same trace split by grid size: paired (two-tensor) launches of a kernel are twice as long as single ones
+    by_grid = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "fq::" in r["Kernel_Name"]:
+            by_grid[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, f"{tag}_kernel_stats_by_grid.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# same rocprofv3 kernel trace, fq:: kernels split by grid size (the larger grid of a kernel = the paired weight+input launch)"])
+        w.writerow(["Name", "Grid_Size_X", "Calls", "AverageNs", "MinNs", "MaxNs"])
+        for (name, grid), v in sorted(by_grid.items()):
+            w.writerow([name, grid, len(v), round(statistics.mean(v), 1), min(v), max(v)])
+
     # 2. PMC traffic
     res = {"unit": "bytes per launch", "correction": "FETCH_SIZE KiB x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1",
            "calibration": {}, "kernels": {}}
@@ -70,7 +91,10 @@ def main():
                 "known_read_bytes": 0 if "write_kernel" in name else KNOWN, "known_write_bytes": 0 if "read_kernel" in name else KNOWN,
                 "FETCH_SIZE_KiB_raw": statistics.median(kbf[name]), "WRITE_SIZE_KiB_raw": statistics.median(kbw.get(name, [0])),
                 "read_bytes_corrected": statistics.median(kbf[name]) * 2 * 1024, "write_bytes": statistics.median(kbw.get(name, [0])) * 1024}
-    bf, bw = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write"))
+    bf, bw = counters(os.path.join(src, "fetch"), True), counters(os.path.join(src, "write"), True)
+    single_grid = {}
+    for (name, grid) in bf:   # the smallest grid of a kernel = its single-tensor launches
+        single_grid[name] = min(grid, single_grid.get(name, grid))
     traffic = {}
 
     def split(vals):
@@ -81,11 +105,20 @@ def main():
         cut = (lo + hi) / 2
         return [v for v in vals if v < cut], [v for v in vals if v >= cut]
 
-    for name in bf:
+    for (name, grid) in sorted(bf):
         if "fq::" not in name:
             continue
-        fv, wv = bf[name], bw.get(name, [])
-        entry = {"launches": len(fv)}
+        fv, wv = bf[(name, grid)], bw.get((name, grid), [])
+        entry = {"launches": len(fv), "grid_size": grid}
+        if grid != single_grid[name]:   # a paired launch (weight + input of a QuantizeLinear)
+            rd, wr = statistics.median(fv) * 2048, (statistics.median(wv) * 1024 if wv else 0)
+            entry.update({"paired_launch": True, "read_bytes": rd, "write_bytes": wr, "total": rd + wr})
+            if "row_reg_kernel" in name and ac_flag(name) == 0:
+                traffic["sym_fwd_pair_w4a8"] = rd + wr
+            elif "ste_mask_kernel" in name:
+                traffic["ste_bwd_pair_w4a8"] = rd + wr
+            res["kernels"][short(name) + f" [grid {grid}]"] = entry
+            continue
         f_lo, f_hi = split(fv)
         w_lo, w_hi = split(wv) if wv else ([], [])
         med = statistics.median
@@ -97,6 +130,10 @@ def main():
             if f_hi:
                 entry["rows_clippable"] = {"read_bytes": med(f_hi) * 2048, "write_bytes": wr, "total": med(f_hi) * 2048 + wr, "launches": len(f_hi)}
                 traffic["ste_bwd_a8"] = entry["rows_clippable"]["total"]
+        elif "row_reg_kernel" in name and ac_flag(name) != 0:
+            rd = med(fv) * 2048
+            wr = med(wv) * 1024 if wv else None
+            entry.update({"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0), "note": "autocast arithmetic"})
         elif "row_reg_kernel" in name:
             # bimodal on the WRITE side in training mode: the A8 leg also writes the 1-bit STE mask
             rd = med(fv) * 2048
@@ -115,7 +152,7 @@ def main():
         d = dur.get(short(name))
         if d:
             entry["avg_duration_ns_unprofiled_trace"] = statistics.mean(d)
-        res["kernels"][short(name)] = entry
+        res["kernels"][short(name) + f" [grid {grid}]"] = entry
     if "sym_fwd_w4" in traffic:
         traffic["sym_fwd_w4_plain"] = traffic["sym_fwd_w4"]
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--autocast", action="store_true", help="run the step under torch.autocast(cuda, bf16), as run_train.sh does")
+    ap.add_argument("--only", default=None, help="run only the implementation whose label equals this (for profiling), W4A8KV4, no checkpointing")
     args = ap.parse_args()
     global AUTOCAST
     AUTOCAST = args.autocast
@@ -75,10 +76,12 @@ def main():
 
     ids = torch.randint(2, 32000, (1, 2048), device="cuda")
     rows = []
-    for wb, ab, kvb in ((4, 8, 4), (8, 8, 8)):
-        for ckpt in (False, True):
+    for wb, ab, kvb in ((4, 8, 4), (8, 8, 8))[: 1 if args.only else 2]:
+        for ckpt in (False, True)[: 1 if args.only else 2]:
             for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
                                          ("llm_qat_amd", UQ, False), ("llm_qat_amd + weight cache", UQ, True)):
+                if args.only and label != args.only:
+                    continue
                 if quant is NoQuant:
                     model = build(quant, args.layers, 32, 32, 32)
                 else:
@@ -90,6 +93,8 @@ def main():
                 print(rows[-1], flush=True)
                 del model
                 torch.cuda.empty_cache()
+    if args.only:
+        return
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "model_step_bench_autocast.json" if AUTOCAST else "model_step_bench.json"), "w"), indent=1)
 
 

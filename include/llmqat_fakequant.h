@@ -152,8 +152,12 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
  *   wide_out  1: y is fp32 [rows, cols], exactly what the reference returns (KV hooks, direct callers)
  *             0: y has the input dtype = that fp32 result rounded once to it -- bit-identical to what F.linear's own
  *                autocast cast makes of it next, so QuantizeLinear can skip the fp32 round trip (2 instead of 4+4+2 B/elem)
- *   row_bounds_out / mask_out  optional training-mode outputs, as in fq_sym_fwd_train (mask_out needs row_bounds_out);
- *             the backward is fq_ste_bwd_mask / fq_ste_bwd on the input dtype (cast an fp32 grad_output first).
+ *   row_bounds_out / mask_out  optional training-mode outputs, as in fq_sym_fwd_train (mask_out needs row_bounds_out).
+ *             wide_out = 0: the backward is fq_ste_bwd_mask / fq_ste_bwd on the input dtype.
+ *             wide_out = 1: the gradient of the fp32 result is fp32 and the autograd engine casts it to the input dtype
+ *             (grad of a bf16 leaf is bf16); fq_ste_bwd_mask_wide does cast + masking in one pass and is the ONLY
+ *             consumer of a mask written with wide_out = 1 (its bit layout follows the fp32 stream: 4 elements per
+ *             lane instead of 8; same buffer size).  Without a mask: cast grad_output, then fq_ste_bwd_rows / fq_ste_bwd.
  *   workspace  fq_rowwise_workspace_bytes(rows, cols, dtype) bytes (only rows longer than 32768 elements use it)
  * Returns FQ_ERR_UNSUPPORTED when a mask is requested for a shape fq_ste_mask_bytes rejects or for misaligned rows.
  */
@@ -168,7 +172,9 @@ int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int 
  * ~2.8 us of fixed cost on MI355X), with results bit-identical to two separate calls.
  *   tensor 0 / tensor 1  same dtype and `cols`; own rows, bit width, outputs.  row_bounds / mask are optional per
  *                        tensor (training mode; a mask needs its row_bounds).
- *   autocast             0: the arithmetic of fq_sym_fwd_train;  1: of fq_sym_fwd_autocast with wide_out = 0
+ *   autocast             0: the arithmetic of fq_sym_fwd_train;  1: of fq_sym_fwd_autocast with wide_out = 0;
+ *                        2: with wide_out = 1 (y0 / y1 are fp32) -- the K and V hooks of the attention block
+ *                        (models/modeling_llama_quant.py:320-327: two SymQuantizer calls on [bsz, q_len, hidden] tensors)
  * Only the register-resident kernels serve pairs: FQ_ERR_UNSUPPORTED for misaligned rows or rows longer than 8192
  * 16-byte vectors (fall back to two calls).
  */
@@ -177,6 +183,18 @@ int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* r
                     int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream);
 /* STE backward of both tensors of a pair in one launch (F.linear's backward produces both gradients together). */
 int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
+                         const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
+                         int64_t cols, float lo, float hi, int dtype, void* stream);
+
+/*
+ * STE backward behind a fp32-result forward (fq_sym_fwd_autocast wide_out = 1 / fq_sym_fwd_pair autocast = 2), the
+ * reference's `grad_input = grad_output.clone(); grad_input[mask] = 0` (models/utils_quant.py:83-87) followed by the
+ * autograd engine's cast of that fp32 gradient to the input's dtype, in one pass:  gx = mask ? 0 : round_to_dtype(g).
+ *   g0 / g1    fp32 [rows, cols];  gx0 / gx1  `dtype` (bf16 / fp16) [rows, cols];  rows1 = 0: one tensor only
+ *   row_bounds / mask   as written by that forward (required)
+ * FQ_ERR_UNSUPPORTED for shapes fq_ste_mask_bytes rejects, cols > 32768, or g not 16-byte / gx not 8-byte aligned.
+ */
+int fq_ste_bwd_mask_wide(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
                          const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
                          int64_t cols, float lo, float hi, int dtype, void* stream);
 

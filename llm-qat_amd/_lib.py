@@ -19,7 +19,7 @@ EXPORTS = (
     "fq_sym_fwd", "fq_asym_fwd", "fq_sym_fwd_debug", "fq_asym_fwd_debug",
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
-    "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair",
+    "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
 )
 ERR_UNSUPPORTED = -8
 
@@ -69,6 +69,8 @@ def _bind(L):
     L.fq_sym_fwd_pair.restype = i32
     L.fq_ste_bwd_mask_pair.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, f32, f32, i32, vp]
     L.fq_ste_bwd_mask_pair.restype = i32
+    L.fq_ste_bwd_mask_wide.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, f32, f32, i32, vp]
+    L.fq_ste_bwd_mask_wide.restype = i32
     return L
 
 

@@ -209,6 +209,7 @@ FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, f
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (bits0 < 2 || bits0 > 31 || bits1 < 2 || bits1 > 31) return fail(FQ_ERR_BITS, "num_bits outside [2, 31]");
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
+    if (autocast < 0 || autocast > 2) return fail(FQ_ERR_ARG, "autocast must be 0, 1 or 2");
     if (autocast && dtype == FQ_DTYPE_F32) return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
     if (rows0 <= 0 || rows1 <= 0 || cols <= 0) return fail(FQ_ERR_SHAPE, "pair launch needs two non-empty tensors");
     if (!x0 || !y0 || !x1 || !y1) return fail(FQ_ERR_NULL, "pair launch: x / y of both tensors required");
@@ -221,7 +222,10 @@ FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, f
     RowArgs a{x0, y0, nullptr, nullptr, row_bounds0, rows0 + rows1, cols, c0.sym, c0.asym, (uint64_t*)mask0, mrw, host_rb(lo, dtype), host_rb(hi, dtype),
               rows0, x1, y1, row_bounds1, (uint64_t*)mask1, c1.sym.qmax};
     hipStream_t st = (hipStream_t)stream;
-    if (autocast) return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(false, a, nullptr, 0, st) : launch_sym_autocast<F16>(false, a, nullptr, 0, st);
+    if (autocast) {
+        const bool wide = autocast == 2;  // y0 / y1 are fp32; masks (if any) in the wide layout, for fq_ste_bwd_mask_wide
+        return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide, a, nullptr, 0, st) : launch_sym_autocast<F16>(wide, a, nullptr, 0, st);
+    }
     switch (dtype) {
         case FQ_DTYPE_F32: return launch_rowwise<F32>(false, true, a, nullptr, 0, st);
         case FQ_DTYPE_F16: return launch_rowwise<F16>(false, true, a, nullptr, 0, st);
@@ -245,6 +249,26 @@ FQ_API int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const 
         case FQ_DTYPE_F16: return launch_ste_mask<F16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
         default: return launch_ste_mask<BF16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
     }
+}
+
+FQ_API int fq_ste_bwd_mask_wide(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
+                                const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
+                                int64_t cols, float lo, float hi, int dtype, void* stream) {
+    if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16) return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward: the input dtype must be bf16 / fp16");
+    if (rows0 < 0 || rows1 < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
+    if (rows0 == 0 && rows1 == 0) return ok();
+    if (cols == 0) return ok();
+    if (rows0 == 0) return fail(FQ_ERR_SHAPE, "a single tensor goes first (rows1 = 0)");
+    if (!g0 || !gx0 || !row_bounds0 || !mask0) return fail(FQ_ERR_NULL, "g / gx / row_bounds / mask must not be NULL");
+    if (rows1 && (!g1 || !gx1 || !row_bounds1 || !mask1)) return fail(FQ_ERR_NULL, "second tensor: all buffers required");
+    if (!mask_row_words(cols, 2)) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
+    lo = host_rb(lo, dtype);
+    hi = host_rb(hi, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const SteSecond sec{rows0, g1, gx1, row_bounds1, (const uint64_t*)mask1};
+    const SteSecond* sp = rows1 ? &sec : nullptr;
+    return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, sp)
+                                  : launch_ste_mask_wide<F16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, sp);
 }
 
 FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,

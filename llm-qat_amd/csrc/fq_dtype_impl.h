@@ -77,13 +77,13 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         const int64_t nvec = a.cols / EPV;
         const int64_t big_rows = pair ? (a.rows0 > a.rows - a.rows0 ? a.rows0 : a.rows - a.rows0) : a.rows;
         const int64_t bytes = big_rows * a.cols * T::ESIZE;
-        if (pair && (AC == 2 || !(vec_ok && nvec <= REG_MAX_VEC)))
-            return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
         if constexpr (AC == 2) {
-            // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced; no STE mask on this path
+            // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced
             const int64_t nh = a.cols / 4;
-            if (!a.mask && aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8) {
+            const bool wide_ok = aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8 &&
+                                 (!pair || (aligned16(a.y1) && (reinterpret_cast<uintptr_t>(a.x1) & 7u) == 0));
+            if (wide_ok) {
                 const bool nts = 3 * bytes >= NT_STORE_MIN_BYTES, ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define W(TPR)                                                                                          \
     {                                                                                                   \
@@ -98,11 +98,26 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
                 if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
                 return ok();
             }
+            if (pair || a.mask)
+                return fail(FQ_ERR_UNSUPPORTED, "fp32-result forward with STE mask / second tensor: rows must be 8-byte aligned, cols %% 4 == 0, cols <= 32768");
+            // other shapes: scalar-load kernel or two passes (bounds only)
+            if (a.cols <= GENERIC_MAX_COLS) {
+                if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, false, AC>), (a.rows + 3) / 4, 256, st, a);
+                else FQ_LAUNCH((row_generic_kernel<DT, 256, false, AC>), a.rows, 256, st, a);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+                return ok();
+            }
+        } else {
+            if (pair && !(vec_ok && nvec <= REG_MAX_VEC))
+                return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
         }
-        if (vec_ok && nvec <= REG_MAX_VEC) {
-            if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
-            else if (bytes >= NT_STORE_MIN_BYTES) launch_reg_ac<DT, AC, false, true>(a, nvec, st);
-            else launch_reg_ac<DT, AC, false, false>(a, nvec, st);
+        if (AC == 1 && vec_ok && nvec <= REG_MAX_VEC) {
+            if constexpr (AC == 1) {
+                if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
+                else if (bytes >= NT_STORE_MIN_BYTES) launch_reg_ac<DT, AC, false, true>(a, nvec, st);
+                else launch_reg_ac<DT, AC, false, false>(a, nvec, st);
+            }
         } else if (a.mask) {
             return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
         } else if (a.cols <= GENERIC_MAX_COLS) {
@@ -276,6 +291,41 @@ int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
 }
 
 template <int DT>
+int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
+                         hipStream_t st, const SteSecond* second) {
+    using T = Ty<DT>;
+    if constexpr (T::ESIZE != 2) {
+        return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward applies to bf16 / fp16 inputs only");
+    } else {
+        const int64_t mrw = mask_row_words(cols, T::ESIZE);
+        auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+        if (!mrw || cols > 32768 || !(aligned16(g) && al8(gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: shape/alignment not served");
+        if (second && !(aligned16(second->g) && al8(second->gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
+        const SteSecond sec = second ? *second : SteSecond{rows, nullptr, nullptr, nullptr, nullptr};
+        const int64_t nh_row = cols / 4;
+        const int64_t chunks = (nh_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
+        int ch = (int)((nh_row + chunks - 1) / chunks);
+        ch = (ch + 63) / 64 * 64;  // every wave covers exactly one 64-half-vector mask group per slot
+        const int hpt = (ch + STE_THREADS - 1) / STE_THREADS;
+        if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
+        const int64_t big_rows = second ? (sec.rows0 > rows - sec.rows0 ? sec.rows0 : rows - sec.rows0) : rows;
+        const int64_t bytes = big_rows * cols * 4;  // the fp32 gradient is the larger stream
+        const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= 2 * NT_STORE_MIN_BYTES;
+#define S(V)                                                                                                                                           \
+    case V:                                                                                                                                            \
+        if (ntl) FQ_LAUNCH((ste_mask_wide_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);        \
+        else if (nts) FQ_LAUNCH((ste_mask_wide_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);  \
+        else FQ_LAUNCH((ste_mask_wide_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);          \
+        break;
+        switch (hpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
+#undef S
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+        return ok();
+    }
+}
+
+template <int DT>
 int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, float cv,
                hipStream_t st) {
     using T = Ty<DT>;
@@ -302,6 +352,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
     template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteSecond*); \
+    template int launch_ste_mask_wide<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteSecond*); \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 
 }  // namespace fq

@@ -91,7 +91,7 @@ template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g
 template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false, int AC = 0>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
     using T = Ty<DT>;
-    static_assert(AC == 0 || (!ASYM && !DBG && T::ESIZE == 2), "autocast arithmetic: Sym on 16-bit tensors");
+    static_assert(AC == 0 || (AC == 1 && !ASYM && !DBG && T::ESIZE == 2), "autocast arithmetic: Sym on 16-bit tensors");
     constexpr int EPV = 16 / T::ESIZE;
     constexpr int NW = TPR / 64;
     __shared__ uint32_t red[3][NW > 1 ? NW : 1];
@@ -217,23 +217,15 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         if constexpr (AC != 0) {  // fp32 arithmetic behind the reciprocal, as autocast makes the reference do
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[e] = sym_elem_autocast(f[e], sr);
-            if constexpr (AC == 2) {  // fp32 result: two 16-byte stores per input vector
-                uint4* y32 = (uint4*)((char*)yb + row * a.cols * 4);
-                if (v < nvec) {
-                    st16<NTS>(&y32[2 * v], make_uint4(as_u(f[0]), as_u(f[1]), as_u(f[2]), as_u(f[3])));
-                    st16<NTS>(&y32[2 * v + 1], make_uint4(as_u(f[4]), as_u(f[5]), as_u(f[6]), as_u(f[7])));
-                }
-            } else {  // rounded once to the tensor dtype
-                uint32_t o[4];
+            uint32_t o[4];  // rounded once to the tensor dtype (the fp32 result has its own kernel below)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    float fd[T::EPD];
+            for (int d = 0; d < 4; ++d) {
+                float fd[T::EPD];
 #pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
-                    o[d] = T::pack(fd);
-                }
-                if (v < nvec) st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
+                for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
+                o[d] = T::pack(fd);
             }
+            if (v < nvec) st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
             continue;
         }
         uint32_t o[4];
@@ -264,8 +256,11 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 // half-vectors (4 elements per lane, 512 B contiguous per wave-instruction) so that each lane's 4 fp32 results
 // are one 16-byte store and a wave-instruction writes 1 KiB contiguous.  (Keeping the 16-byte loads makes every
 // store instruction touch half of each 128-byte line: 99 us instead of ~50 us on the 90 MB tensor.)
-// Records row bounds; no STE mask (its layout is defined on 16-byte vectors) -- the backward re-reads x, which
-// for the tensors that take this path (the KV-cache hooks, 16 MB) is the cheaper trade.
+// Records row bounds and, on request, the STE mask in its own "half-vector" layout (the 4 elements of a lane's
+// 8-byte load take the place of the 16-byte vector's EPV elements: groups of 64 half-vectors, 4 words per group;
+// never more words per row than the 16-byte layout, so fq_ste_mask_bytes() sizes both).  Its consumer is
+// ste_mask_wide_kernel, whose fp32 gradient is read with the same 4-elements-per-lane mapping.
+// Serves two tensors per launch like row_reg_kernel (the K and V hooks: modeling_llama_quant.py:320-327).
 // ------------------------------------------------------------------------------------
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <bool NT> __device__ __forceinline__ uint2 ld8(const uint2* p) {
@@ -274,6 +269,14 @@ template <bool NT> __device__ __forceinline__ uint2 ld8(const uint2* p) {
         return make_uint2(v.x, v.y);
     } else {
         return *p;
+    }
+}
+template <bool NT> __device__ __forceinline__ void st8(uint2* p, uint2 v) {
+    if constexpr (NT) {
+        u32x2_t w = {v.x, v.y};
+        __builtin_nontemporal_store(w, (u32x2_t*)p);
+    } else {
+        *p = v;
     }
 }
 
@@ -293,9 +296,22 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
         row = blockIdx.x;
         t = threadIdx.x;
     }
+    const void* xb = a.x;  // which tensor of the launch this row belongs to (wave-uniform), as in row_reg_kernel
+    void* yb = a.y;
+    float* bnd = a.bounds;
+    uint64_t* msk = a.mask;
+    float qmax = a.sym.qmax;
+    if (row >= a.rows0) {
+        row -= a.rows0;
+        xb = a.x1;
+        yb = a.y1;
+        bnd = a.bounds1;
+        msk = a.mask1;
+        qmax = a.qmax1;
+    }
     const int nh = (int)(a.cols / 4);
-    const uint2* __restrict__ xr = (const uint2*)((const char*)a.x + row * a.cols * 2);
-    uint4* __restrict__ yr = (uint4*)((char*)a.y + row * a.cols * 4);
+    const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row * a.cols * 2);
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row * a.cols * 4);
     uint2 r[HPT];
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
@@ -307,19 +323,32 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
 #pragma unroll
     for (int i = 0; i < HPT; ++i) acc = T::absmax_acc(T::absmax_acc(acc, r[i].x), r[i].y);
     const float m = as_f(block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red));
-    const SymRow sr = sym_row_autocast<DT>(m, a.sym.qmax);
-    if (t == 0 && a.bounds) {
-        a.bounds[2 * row] = m;
-        a.bounds[2 * row + 1] = -m;
+    const SymRow sr = sym_row_autocast<DT>(m, qmax);
+    if (t == 0 && bnd) {
+        bnd[2 * row] = m;
+        bnd[2 * row + 1] = -m;
     }
+    const bool want_mask = msk && !((m < a.hi) && (-m > a.lo));  // wave-uniform; NaN row: mask written, all bits 0
+    const bool sym_clip = a.lo == -a.hi;
+    uint64_t* mrow = msk + row * a.mask_row_words;
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
         const int h = t + i * TPR;
-        float f0[2], f1[2];
-        T::unpack(r[i].x, f0);
-        T::unpack(r[i].y, f1);
-        const uint4 o = make_uint4(as_u(sym_elem_autocast(f0[0], sr)), as_u(sym_elem_autocast(f0[1], sr)),
-                                   as_u(sym_elem_autocast(f1[0], sr)), as_u(sym_elem_autocast(f1[1], sr)));
+        float f[4];
+        {
+            float f0[2], f1[2];
+            T::unpack(r[i].x, f0);
+            T::unpack(r[i].y, f1);
+            f[0] = f0[0], f[1] = f0[1], f[2] = f1[0], f[3] = f1[1];
+        }
+        if (want_mask && (h - (t & 63) < nh)) {  // wave-uniform: this wave's 64-half-vector group exists
+            const int hc = h < nh ? h : nh - 1;
+            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(hc >> 6) * 4;
+            if (sym_clip) ste_mask_store<4, true>(f, a.lo, a.hi, gw, t & 63);
+            else ste_mask_store<4, false>(f, a.lo, a.hi, gw, t & 63);
+        }
+        const uint4 o = make_uint4(as_u(sym_elem_autocast(f[0], sr)), as_u(sym_elem_autocast(f[1], sr)),
+                                   as_u(sym_elem_autocast(f[2], sr)), as_u(sym_elem_autocast(f[3], sr)));
         if (h < nh) st16<NTS>(&yr[h], o);
     }
 }
@@ -820,6 +849,62 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
             const uint4 o = ste_mask_apply<DT>(rg[i], mw);
             if (v < nvec) st16<NTS>(&or_[v], o);
         }
+    }
+}
+
+// STE backward of a fp32-result (autocast) forward: the gradient arrives in fp32 (the dtype of the forward's result),
+// the input's gradient leaves in the input's 16-bit dtype -- the autograd engine's cast and the masking in one pass
+// (read 4 B + write 2 B per element instead of a cast kernel followed by a 16-bit STE kernel).  Mask in the wide
+// forward's layout: half-vectors (4 elements) in groups of 64, 4 words per group.  ch is a multiple of 64.
+template <int DT, int HPT, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nh_row,
+                                                                    int64_t chunks, int ch, const float* __restrict__ bounds,
+                                                                    const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
+                                                                    float hi, SteSecond second) {
+    using T = Ty<DT>;
+    static_assert(T::ESIZE == 2, "fp32 gradient in, 16-bit gradient out");
+    int64_t row = blockIdx.x / chunks;
+    if (row >= second.rows0) {  // block-uniform
+        row -= second.rows0;
+        g = second.g;
+        gx = second.gx;
+        bounds = second.bounds;
+        mask = second.mask;
+    }
+    const int64_t hs = (blockIdx.x % chunks) * ch;
+    const int64_t off = row * nh_row + hs;
+    const uint4* gr = (const uint4*)g + off;
+    uint2* or_ = (uint2*)gx + off;
+    const int64_t rem = nh_row - hs;
+    const int nh = (int)(rem < ch ? rem : ch);
+    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+    const bool safe = (ub < hi) && (lb > lo);
+    const int t = threadIdx.x;
+    uint4 rg[HPT];
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        int h = t + i * STE_THREADS;
+        h = h < nh ? h : nh - 1;
+        rg[i] = ld16<NTL>(&gr[h]);
+    }
+    const uint64_t* mrow = mask + row * mask_row_words;
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const int h = t + i * STE_THREADS;
+        const float f0[2] = {as_f(rg[i].x), as_f(rg[i].y)}, f1[2] = {as_f(rg[i].z), as_f(rg[i].w)};
+        uint32_t w0 = T::pack(f0), w1 = T::pack(f1);
+        if (!safe) {
+            const int hc = h < nh ? h : nh - 1;
+            const int64_t grp = __builtin_amdgcn_readfirstlane((int)((hs + hc) >> 6));
+            uint64_t mw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mw[e] = mrow[grp * 4 + e];  // wave-uniform address -> scalar loads
+            w0 &= (__builtin_amdgcn_inverse_ballot_w64(mw[0]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
+                  (__builtin_amdgcn_inverse_ballot_w64(mw[1]) ? 0x0000FFFFu : 0xFFFFFFFFu);
+            w1 &= (__builtin_amdgcn_inverse_ballot_w64(mw[2]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
+                  (__builtin_amdgcn_inverse_ballot_w64(mw[3]) ? 0x0000FFFFu : 0xFFFFFFFFu);
+        }
+        if (h < nh) st8<NTS>(&or_[h], make_uint2(w0, w1));
     }
 }
 

@@ -39,6 +39,10 @@ template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* g
 template <int DT>
 FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
                               const uint64_t* mask, hipStream_t st, const SteSecond* second = nullptr);
+// STE backward of a fp32-result forward: g is fp32, gx has the (16-bit) dtype DT; mask in the wide forward's layout
+template <int DT>
+FQ_HIDDEN int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
+                                   const uint64_t* mask, hipStream_t st, const SteSecond* second = nullptr);
 template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);

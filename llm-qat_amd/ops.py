@@ -129,6 +129,12 @@ def _mask_bytes(rows, cols, code):
     return v
 
 
+def _aligned(g):
+    """contiguous and 16-byte aligned (a gradient can be an offset view into a larger buffer)"""
+    g = g if g.is_contiguous() else g.contiguous()
+    return g.clone() if g.data_ptr() & 15 else g
+
+
 def train_forward(kind, x, num_bits, layerwise, lo, hi):
     """-> (y, side, rows, cols) or None.  `side` is one uint8 buffer: float[rows][2] bounds followed by the mask."""
     if x.device.type != "cuda":
@@ -166,7 +172,7 @@ def train_backward(grad_output, side, rows, cols, lo, hi):
     code = _DTYPES.get(grad_output.dtype)
     if code is None or grad_output.device.type != "cuda":
         _prep(grad_output, "ste_backward")
-    g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
+    g = _aligned(grad_output)
     gx = torch.empty_like(g)
     sp = side.data_ptr()
     dev = g.device.index
@@ -180,6 +186,22 @@ def train_backward(grad_output, side, rows, cols, lo, hi):
                                torch.cuda.current_stream().cuda_stream)
     if rc:
         _lib.check(rc, "ste_backward_mask")
+    return gx
+
+
+def train_backward_wide(grad_output, side, rows, cols, lo, hi, out_dtype):
+    """STE backward behind a fp32-result (autocast) forward: fp32 grad_output -> masked gradient in the input's dtype
+    (the autograd engine's cast folded in; fq_ste_bwd_mask_wide).  side = bounds + mask of THAT forward."""
+    code = _DTYPES.get(out_dtype)
+    if code is None or grad_output.device.type != "cuda":
+        raise TypeError(f"ste_backward[wide]: unsupported input dtype {out_dtype} / device {grad_output.device}")
+    g = _aligned(grad_output if grad_output.dtype == torch.float32 else grad_output.float())
+    gx = torch.empty(g.shape, dtype=out_dtype, device=g.device)
+    sp = side.data_ptr()
+    with _DeviceOf(g):
+        rc = _lib.lib().fq_ste_bwd_mask_wide(g.data_ptr(), gx.data_ptr(), rows, sp, sp + rows * 8, None, None, 0, None, None,
+                                             cols, float(lo), float(hi), code, _stream(g))
+    _lib.check(rc, "ste_backward_mask_wide")
     return gx
 
 
@@ -207,7 +229,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     with _DeviceOf(x):
         st = _stream(x)
         rc = _lib.ERR_UNSUPPORTED
-        if train == "mask" and xc is x and not wide:  # the fp32-result kernel records bounds only (see fq_kernels.h)
+        if train == "mask" and xc is x:  # (a wide result's mask has its own layout: backward = train_backward_wide)
             mbytes = _mask_bytes(rows, cols, code)
             if mbytes:
                 side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
@@ -231,34 +253,38 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     return y, side, rows, cols, got
 
 
-def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x):
-    """QuantizeLinear's two operands in ONE launch (fq_sym_fwd_pair): weight [out, in] per output channel and input
-    [..., in] per token share the row length.  -> (wq, xq, side_w, side_x, rows_w, rows_x, cols) or None when the pair
-    is not served (different dtypes / devices, misaligned, non-contiguous, rows too long): use two calls then.
-    side_* (row bounds + STE mask, as in train_forward) is produced only for the operands that need a gradient."""
+def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
+    """Two tensors with the same row length in ONE launch (fq_sym_fwd_pair): QuantizeLinear's weight [out, in] (per
+    output channel) + input [..., in] (per token), or the attention block's K + V (per token).
+    -> (wq, xq, side_w, side_x, rows_w, rows_x, cols) or None when the pair is not served (different dtypes / devices,
+    misaligned, non-contiguous, rows too long): use two calls then.
+    side_* (row bounds + STE mask, as in train_forward) is produced only for the operands that need a gradient.
+    wide: under autocast, return the reference's fp32 results (else those rounded once to the operand dtype)."""
     if w.dtype != x.dtype or w.device != x.device or not (w.is_cuda and w.is_contiguous() and x.is_contiguous()):
         return None
     code = _DTYPES.get(w.dtype)
-    if code is None or w.dim() != 2 or x.dim() < 1 or x.dim() > 3 or x.shape[-1] != w.shape[1] or x.numel() == 0 or w.numel() == 0:
+    if code is None or not (1 <= w.dim() <= 3 and 1 <= x.dim() <= 3) or x.shape[-1] != w.shape[-1] or x.numel() == 0 or w.numel() == 0:
         return None
-    cols = w.shape[1]
-    rows_w, rows_x = w.shape[0], x.numel() // cols
+    cols = w.shape[-1]
+    rows_w, rows_x = w.numel() // cols, x.numel() // cols
     mw, mx = _mask_bytes(rows_w, cols, code), _mask_bytes(rows_x, cols, code)
     if not mw or not mx:
         return None
     ac = autocast_active(w)
+    wide = bool(wide and ac)
     L = _lib.lib()
-    wq, xq = torch.empty_like(w), torch.empty_like(x)
+    odt = torch.float32 if wide else w.dtype
+    wq, xq = torch.empty(w.shape, dtype=odt, device=w.device), torch.empty(x.shape, dtype=odt, device=w.device)
     side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device) if need_w else None
     side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device) if need_x else None
     pw, px = (side_w.data_ptr() if need_w else None), (side_x.data_ptr() if need_x else None)
     with _DeviceOf(w):
         rc = L.fq_sym_fwd_pair(w.data_ptr(), wq.data_ptr(), rows_w, int(w_bits), pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
                                x.data_ptr(), xq.data_ptr(), rows_x, int(a_bits), px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
-                               cols, code, _semantics, 1 if ac else 0, float(lo), float(hi), _stream(w))
+                               cols, code, _semantics, (2 if wide else 1) if ac else 0, float(lo), float(hi), _stream(w))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "quantize_linear_pair")
+    _lib.check(rc, "quantize_pair")
     return wq, xq, side_w, side_x, rows_w, rows_x, cols
 
 
@@ -268,8 +294,7 @@ def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi):
         g, side, rows = (gw, side_w, rows_w) if gx is None else (gx, side_x, rows_x)
         return (train_backward(g, side, rows, cols, lo, hi), None) if gx is None else (None, train_backward(g, side, rows, cols, lo, hi))
     code = _DTYPES.get(gw.dtype)
-    gw = gw if gw.is_contiguous() else gw.contiguous()
-    gx = gx if gx.is_contiguous() else gx.contiguous()
+    gw, gx = _aligned(gw), _aligned(gx)
     ow, ox = torch.empty_like(gw), torch.empty_like(gx)
     pw, px = side_w.data_ptr(), side_x.data_ptr()
     with _DeviceOf(gw):
@@ -278,6 +303,24 @@ def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi):
     if rc == _lib.ERR_UNSUPPORTED:
         return train_backward(gw, side_w, rows_w, cols, lo, hi), train_backward(gx, side_x, rows_x, cols, lo, hi)
     _lib.check(rc, "quantize_linear_pair_backward")
+    return ow, ox
+
+
+def pair_backward_wide(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, out_dtype):
+    """pair_backward behind a wide (fp32-result) pair_forward: fp32 gradients in, gradients in the operands' dtype out."""
+    if gw is None or gx is None:
+        if gx is None:
+            return train_backward_wide(gw, side_w, rows_w, cols, lo, hi, out_dtype), None
+        return None, train_backward_wide(gx, side_x, rows_x, cols, lo, hi, out_dtype)
+    code = _DTYPES.get(out_dtype)
+    gw = _aligned(gw if gw.dtype == torch.float32 else gw.float())
+    gx = _aligned(gx if gx.dtype == torch.float32 else gx.float())
+    ow, ox = torch.empty(gw.shape, dtype=out_dtype, device=gw.device), torch.empty(gx.shape, dtype=out_dtype, device=gx.device)
+    pw, px = side_w.data_ptr(), side_x.data_ptr()
+    with _DeviceOf(gw):
+        rc = _lib.lib().fq_ste_bwd_mask_wide(gw.data_ptr(), ow.data_ptr(), rows_w, pw, pw + rows_w * 8,
+                                             gx.data_ptr(), ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, float(lo), float(hi), code, _stream(gw))
+    _lib.check(rc, "quantize_pair_backward_wide")
     return ow, ox
 
 

@@ -62,7 +62,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         ctx.grad_dtype = input.dtype  # the engine casts the reference's fp32 gradient to the input dtype; do it up front
         ctx.clip, ctx.rows_cols, ctx.row_bounds = (lo, hi), (rows, cols), None
         if got == "mask":
-            ctx.fq_mode, ctx.side = "mask", side
+            ctx.fq_mode, ctx.side = ("mask" if narrow else "mask_wide"), side  # a fp32 result's mask has its own layout
             return out
         ctx.save_for_backward(input, clip_val)
         ctx.fq_mode = "plain"
@@ -99,6 +99,10 @@ class _FakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
+        if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
+            lo, hi = ctx.clip
+            rows, cols = ctx.rows_cols
+            return ops.train_backward_wide(grad_output, ctx.side, rows, cols, lo, hi, ctx.grad_dtype), None, None, None
         if ctx.grad_dtype is not None and grad_output.dtype != ctx.grad_dtype:
             grad_output = grad_output.to(ctx.grad_dtype)  # autocast: fp32 grad of the fp32 output; zeroing commutes with the cast
         if ctx.fq_mode == "mask":
@@ -248,9 +252,10 @@ class _PairNode(torch.autograd.Function):
     """Autograd node over the results of one ops.pair_forward launch (weight and input of a QuantizeLinear)."""
 
     @staticmethod
-    def forward(ctx, weight, input, res):
+    def forward(ctx, weight, input, res, clip=(-2.0, 2.0)):
         wq, xq, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
-        ctx.dtype = weight.dtype
+        ctx.dtype, ctx.clip = weight.dtype, clip
+        ctx.wide = wq.dtype != weight.dtype  # fp32 results under autocast (the K / V hooks): fp32 gradients come back
         ctx.set_materialize_grads(False)
         return wq.view_as(wq), xq.view_as(xq)
 
@@ -258,12 +263,42 @@ class _PairNode(torch.autograd.Function):
     def backward(ctx, gw, gx):
         _bwd_epoch[0] += 1
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        lo, hi = ctx.clip
+        if ctx.wide:
+            gw, gx = (gw if need_w else None), (gx if need_x else None)
+            if gw is None and gx is None:
+                return None, None, None, None
+            ow, ox = ops.pair_backward_wide(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
+            return ow, ox, None, None
         gw = gw.to(ctx.dtype) if (need_w and gw is not None and gw.dtype != ctx.dtype) else (gw if need_w else None)
         gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
         if gw is None and gx is None:
-            return None, None, None
-        ow, ox = ops.pair_backward(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, -2.0, 2.0)
-        return ow, ox, None
+            return None, None, None, None
+        ow, ox = ops.pair_backward(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi)
+        return ow, ox, None, None
+
+
+def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
+    """The two KV-cache hooks of the attention block (models/modeling_llama_quant.py:320-327),
+
+        key_states   = self.act_quantizer_k.apply(key_states,   self.act_clip_val_k, self.kv_bits, False)
+        value_states = self.act_quantizer_v.apply(value_states, self.act_clip_val_v, self.kv_bits, False)
+
+    in ONE launch forward and one backward (K and V are [bsz, q_len, hidden] tensors of the same dtype: same row
+    length, same launch shape).  Results and gradients are bit-identical to the two calls; under autocast both come
+    back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served."""
+    k, v = key_states, value_states
+    lo, hi = _clip_pair(clip_val_k)
+    if (_PAIR and _BACKWARD_MODE == "mask" and k.is_cuda and _clip_pair(clip_val_v) == (lo, hi) and 2 <= num_bits < 32
+            and k.dim() <= 3 and v.dim() <= 3):
+        grad = torch.is_grad_enabled()
+        need_k, need_v = grad and k.requires_grad, grad and v.requires_grad
+        res = ops.pair_forward(k, v, num_bits, num_bits, lo, hi, need_k, need_v, wide=True)
+        if res is not None:
+            if need_k or need_v:
+                return _PairNode.apply(k, v, res, (lo, hi))
+            return res[0], res[1]
+    return (SymQuantizer.apply(k, clip_val_k, num_bits, False), SymQuantizer.apply(v, clip_val_v, num_bits, False))
 
 
 class _ReuseQuantizedWeight(torch.autograd.Function):

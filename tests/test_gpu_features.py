@@ -402,3 +402,45 @@ def test_paired_operand_launch_is_transparent(pkg, dtype, autocast):
             b = mods[0](xs)
             pkg.pair_operands(True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_kv_hooks_in_one_launch(pkg, dtype, autocast):
+    """quantize_kv(K, V, ...) == the two SymQuantizer.apply calls of modeling_llama_quant.py:320-327, bit for bit in
+    values and gradients (fp32 results under autocast, like the reference), with one launch each way instead of two."""
+    from llm_qat_amd.utils_quant import SymQuantizer, quantize_kv
+    torch.manual_seed(1)
+    clip = torch.tensor([-2.0, 2.0])
+    k0 = (torch.randn(2, 96, 1024, device="cuda") * 1.2).to(dtype)
+    v0 = (torch.randn(2, 96, 1024, device="cuda") * 0.8).to(dtype)
+    v0[1, 3, 7] = 2.0
+    gk, gv = torch.randn(2, 96, 1024, device="cuda"), torch.randn(2, 96, 1024, device="cuda")
+    out = {}
+    for one in (False, True):
+        k, v = k0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+        with Counter(pkg.ops, ["pair_forward", "pair_backward", "pair_backward_wide", "train_forward", "train_backward", "train_backward_wide",
+                               "sym_forward_autocast"]) as c:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                if one:
+                    kq, vq = quantize_kv(k, v, clip, clip, 4)
+                else:
+                    kq, vq = SymQuantizer.apply(k, clip, 4, False), SymQuantizer.apply(v, clip, 4, False)
+            wide = autocast and dtype == torch.bfloat16
+            assert kq.dtype == vq.dtype == (torch.float32 if wide else dtype)
+            torch.autograd.backward([kq, vq], [gk.to(kq.dtype), gv.to(vq.dtype)])
+        out[one] = (kq.detach(), vq.detach(), k.grad, v.grad, c.n)
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    assert out[False][3][1, 3, 7] == 0
+    assert out[False][4] == 4 and out[True][4] == 2, (out[False][4], out[True][4])
+    # only V needs a gradient; no-grad; different clips fall back to two calls
+    k, v = k0.clone(), v0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        kq, vq = quantize_kv(k, v, clip, clip, 4)
+    vq.backward(gv.to(vq.dtype))
+    assert torch.equal(v.grad, out[False][3]) and torch.equal(kq, out[False][0])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        kq, vq = quantize_kv(k0, v0, clip, clip, 4)
+        k2, v2 = quantize_kv(k0, v0, clip, torch.tensor([-1.0, 1.0]), 4)
+    assert torch.equal(kq, out[False][0]) and torch.equal(vq, out[False][1]) and torch.equal(k2, kq) and torch.equal(v2, vq)

@@ -607,3 +607,76 @@ def test_layerwise_and_long_rows_under_autocast_vs_live_aten(ops, dtype):
         res.append((o.detach(), x.grad, m.weight.grad))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_wide_result_mask_path_vs_oracle(ops, dtype):
+    """fp32-result (autocast) forward with its own STE mask + fq_ste_bwd_mask_wide (fp32 gradient in, 16-bit gradient
+    out, never reading x), single tensors and K/V-style pairs, through the C ABI: forward bit-equal to the oracle's
+    autocast chain, gradient bit-equal to oracle-STE applied to the gradient rounded to the input dtype (the autograd
+    engine's cast).  Partial 64-half-vector groups, multi-chunk rows, safe / unsafe / NaN rows, asymmetric clips."""
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    code = {"bf16": _lib.DTYPE_BF16, "fp16": _lib.DTYPE_F16}[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(78)
+
+    def side(rows, cols):
+        mb = L.fq_ste_mask_bytes(rows, cols, code)
+        assert mb
+        return torch.zeros(rows * 8 + mb, dtype=torch.uint8, device="cuda"), mb
+
+    def make(shape):
+        x_np, x = make_input(rng, shape, dtype, "mixed")
+        if shape[0] > 2:
+            x[1, shape[1] // 2] = float("nan")
+            x[2, 0] = 2.0
+            x[2, shape[1] - 1] = -2.0
+            x_np = np_from(x)
+        g32 = torch.randn(shape, device="cuda") * 1e-3
+        return x_np, x, g32
+
+    def want_grad(g32, x_np, lo, hi):
+        return O.ste_bwd(np_from(g32.to(TD[dtype])), x_np, lo, hi, dtype)
+
+    for cols in (8, 264, 512, 520, 4096, 11008, 13824, 32768):
+        for lo, hi, bits in ((-2.0, 2.0, 8), (-0.5, 0.75, 4)):
+            r0, r1 = 5, 3
+            x0_np, x0, g0 = make((r0, cols))
+            x1_np, x1, g1 = make((r1, cols))
+            # single tensor: fq_sym_fwd_autocast(wide_out=1, mask) -> fq_ste_bwd_mask_wide(rows1 = 0)
+            y = torch.empty(r0, cols, device="cuda")
+            s0, mb0 = side(r0, cols)
+            rc = L.fq_sym_fwd_autocast(x0.data_ptr(), y.data_ptr(), r0, cols, bits, code, 1, lo, hi, s0.data_ptr(), s0.data_ptr() + r0 * 8, mb0, None, 0, st)
+            _lib.check(rc, "wide fwd")
+            yo, _ = O.sym_fwd_autocast(x0_np, r0, cols, bits, dtype, wide=True)
+            assert bits_equal(np_from(y).reshape(yo.shape), yo, "fp32"), f"{dtype} cols={cols} wide fwd"
+            gx = torch.empty(r0, cols, device="cuda", dtype=TD[dtype])
+            rc = L.fq_ste_bwd_mask_wide(g0.data_ptr(), gx.data_ptr(), r0, s0.data_ptr(), s0.data_ptr() + r0 * 8, None, None, 0, None, None,
+                                        cols, lo, hi, code, st)
+            _lib.check(rc, "wide bwd")
+            want = want_grad(g0, x0_np, lo, hi)
+            assert bits_equal(np_from(gx), want, dtype), f"{dtype} cols={cols} clip=({lo},{hi}) wide grad: {mismatch_report(np_from(gx), want, dtype)}"
+            # pair (K and V): fq_sym_fwd_pair(autocast=2) -> fq_ste_bwd_mask_wide with both tensors
+            y0, y1 = torch.empty(r0, cols, device="cuda"), torch.empty(r1, cols, device="cuda")
+            s0, mb0 = side(r0, cols)
+            s1, mb1 = side(r1, cols)
+            rc = L.fq_sym_fwd_pair(x0.data_ptr(), y0.data_ptr(), r0, bits, s0.data_ptr(), s0.data_ptr() + r0 * 8, mb0,
+                                   x1.data_ptr(), y1.data_ptr(), r1, bits, s1.data_ptr(), s1.data_ptr() + r1 * 8, mb1,
+                                   cols, code, 0, 2, lo, hi, st)
+            _lib.check(rc, "wide pair fwd")
+            yo1, _ = O.sym_fwd_autocast(x1_np, r1, cols, bits, dtype, wide=True)
+            assert bits_equal(np_from(y0).reshape(yo.shape), yo, "fp32") and bits_equal(np_from(y1).reshape(yo1.shape), yo1, "fp32"), f"{dtype} cols={cols} pair fwd"
+            gx0, gx1 = torch.empty(r0, cols, device="cuda", dtype=TD[dtype]), torch.empty(r1, cols, device="cuda", dtype=TD[dtype])
+            rc = L.fq_ste_bwd_mask_wide(g0.data_ptr(), gx0.data_ptr(), r0, s0.data_ptr(), s0.data_ptr() + r0 * 8,
+                                        g1.data_ptr(), gx1.data_ptr(), r1, s1.data_ptr(), s1.data_ptr() + r1 * 8, cols, lo, hi, code, st)
+            _lib.check(rc, "wide pair bwd")
+            assert bits_equal(np_from(gx0), want, dtype), f"{dtype} cols={cols} pair grad 0"
+            want1 = want_grad(g1, x1_np, lo, hi)
+            assert bits_equal(np_from(gx1), want1, dtype), f"{dtype} cols={cols} pair grad 1: {mismatch_report(np_from(gx1), want1, dtype)}"
+    # shapes the wide mask path does not serve are refused, not mis-served
+    x = torch.randn(2, 40000, device="cuda").to(TD[dtype])
+    y = torch.empty(2, 40000, device="cuda")
+    s, mb = side(2, 40000)
+    rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), 2, 40000, 8, code, 1, -2.0, 2.0, s.data_ptr(), s.data_ptr() + 16, mb, None, 0, st)
+    assert rc == _lib.ERR_UNSUPPORTED

@@ -135,3 +135,31 @@ def test_dropin_under_checkpointing_and_autocast(reentrant):
         assert torch.equal(l, l_ref), (cache, l.item(), l_ref.item())
         for a, b, (n, _) in zip(g, g_ref, ours.named_parameters()):
             assert torch.equal(a, b), (cache, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("autocast", [False, True])
+def test_dropin_with_kv_hooks_in_one_launch(autocast):
+    """The optional call-site change of INTEGRATION.md (K and V through quantize_kv): the whole step stays bit-identical
+    to the eager chain, plain bf16 and under bf16 autocast (where K / V come back in fp32, as in the reference)."""
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        ref = TL.load_deterministic(TL.TinyLlama(TL.EagerQuant(), w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+        ours = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+        outs = []
+        for m, one in ((ref, False), (ours, True)):
+            TL.KV_ONE_LAUNCH = one
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                loss, logits = m(ids, labels=ids)
+            loss.backward()
+            outs.append((loss.detach(), logits.detach()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for (n, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p.grad, q.grad), n
+    finally:
+        TL.KV_ONE_LAUNCH = False
+        llm_qat_amd.set_semantics("cpu_eager")

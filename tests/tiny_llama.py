@@ -33,6 +33,9 @@ class RMSNorm(nn.Module):
         return self.weight * h
 
 
+KV_ONE_LAUNCH = False  # tests flip this: use quant.quantize_kv (when the quant module has one) for the K / V hooks
+
+
 def rope_tables(head_dim, seq_len, device, dtype, base=10000):
     inv = 1.0 / (base ** (torch.arange(0, head_dim, 2, device=device).float() / head_dim))
     ang = torch.einsum("i,j->ij", torch.arange(seq_len, device=device, dtype=inv.dtype), inv)
@@ -54,6 +57,7 @@ class Attention(nn.Module):
         self.q_proj, self.k_proj, self.v_proj, self.o_proj = mk(), mk(), mk(), mk()
         self.kv_bits = kv_bits
         self.kv_quant = quant.SymQuantizer
+        self.quant_module = quant
         self.clip = torch.tensor([-2.0, 2.0])
 
     def forward(self, h):
@@ -62,8 +66,12 @@ class Attention(nn.Module):
         k = self.k_proj(h)
         v = self.v_proj(h)
         if self.kv_bits < 32:  # per token across all heads, before RoPE
-            k = self.kv_quant.apply(k, self.clip, self.kv_bits, False)
-            v = self.kv_quant.apply(v, self.clip, self.kv_bits, False)
+            kv_pair = getattr(self.quant_module, "quantize_kv", None) if KV_ONE_LAUNCH else None
+            if kv_pair is not None:  # the two-line call-site change INTEGRATION.md describes (K and V in one launch)
+                k, v = kv_pair(k, v, self.clip, self.clip, self.kv_bits)
+            else:
+                k = self.kv_quant.apply(k, self.clip, self.kv_bits, False)
+                v = self.kv_quant.apply(v, self.clip, self.kv_bits, False)
         k = k.view(b, t, self.nh, self.hd).transpose(1, 2)
         v = v.view(b, t, self.nh, self.hd).transpose(1, 2)
         cos, sin = rope_tables(self.hd, t, h.device, v.dtype)

@@ -190,7 +190,23 @@ struct SymConst {   // launch-uniform
 };
 struct SymRow {
     float s, t2, rinv;
+    bool mk;  // t2 lies where div_exact() is proven equal to the IEEE quotient (wave-uniform)
 };
+// x / b for a per-row (or launch-wide) divisor b WITHOUT the IEEE-divide sequence (~10 VALU ops + v_div_scale /
+// v_div_fmas / v_div_fixup): Markstein's correction of a reciprocal multiply.  With r = RN(1/b),
+//     q0 = RN(x * r) ; e = fma(-q0, b, x) (exact) ; q = RN(q0 + e * r)
+// is the correctly rounded quotient -- bit-identical to the division, signed zeros included (`e == 0` keeps the sign
+// of a zero numerator; NaN propagates; an infinite numerator returns q0 = +-inf).  Preconditions, both enforced by the callers: r is a NORMAL number (b <= 2^100)
+// and e does not underflow (|x| >= 2^-101); the quantizers guarantee the second whenever the quotient can still
+// influence a bin (divisor >= 2^-60: a quotient below 2^-32 rounds to bin 0 for every bit width).
+// Checked against the division in tests/c_host/markstein_check.c (10^8 quotients).
+__device__ __forceinline__ bool div_exact_ok(float b) { return b >= 0x1p-60f && b <= 0x1p100f; }  // false for NaN
+__device__ __forceinline__ float div_exact(float x, float b, float r) {
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-q0, b, x);
+    // an infinite numerator (fp16 bins beyond 65504 round to inf) gives q0 = +-inf = the quotient, but e = NaN
+    return (e == 0.0f || __builtin_fabsf(q0) == __builtin_inff()) ? q0 : __builtin_fmaf(e, r, q0);
+}
 // utils_quant.py:71-72:  s = reciprocal(max + 1e-6) * qmax ;  divisor = s + 1e-6
 template <int DT> __device__ __forceinline__ SymRow sym_row(float m, SymConst k) {
     using T = Ty<DT>;
@@ -199,7 +215,8 @@ template <int DT> __device__ __forceinline__ SymRow sym_row(float m, SymConst k)
     const float rc = T::rb(1.0f / t1);  // IEEE divide
     r.s = T::rb(rc * k.qmax);
     r.t2 = T::rb(r.s + k.c6);
-    r.rinv = 1.0f / r.t2;  // only used by the bf16 FAST path (exactness argument: DESIGN.md)
+    r.rinv = 1.0f / r.t2;  // bf16 FAST path: plain multiply (exactness argument: DESIGN.md); fp16: div_exact()
+    r.mk = div_exact_ok(r.t2);
     return r;
 }
 
@@ -215,16 +232,10 @@ template <int DT> __device__ __forceinline__ SymRow sym_row_autocast(float m, fl
     r.s = (1.0f / t1) * qmax;
     r.t2 = r.s + 1e-6f;
     r.rinv = 1.0f / r.t2;
+    r.mk = true;  // t2 = s + 1e-6 with s in [0, 2^31 * 1e6]: always inside div_exact()'s range (or NaN, which propagates)
     return r;
 }
-// idx / t2 without the IEEE-divide sequence: Markstein's correction of a reciprocal multiply is the correctly
-// rounded quotient (r.rinv is the correctly rounded 1/t2); `e == 0` keeps the sign of a zero numerator.
-// Checked against the division on 9e7 quotients in tests/c_host/markstein_check.c.
-__device__ __forceinline__ float div_by_row(float a, const SymRow& r) {
-    const float q0 = a * r.rinv;
-    const float e = __builtin_fmaf(-q0, r.t2, a);
-    return e == 0.0f ? q0 : __builtin_fmaf(e, r.rinv, q0);
-}
+__device__ __forceinline__ float div_by_row(float a, const SymRow& r) { return div_exact(a, r.t2, r.rinv); }
 __device__ __forceinline__ float sym_elem_autocast(float x, const SymRow& r) { return div_by_row(__builtin_rintf(x * r.s), r); }
 
 struct AsymConst {
@@ -235,6 +246,7 @@ struct AsymConst {
 };
 struct AsymRow {
     float mn, al, a, ra;
+    bool mk;  // a lies where div_exact() equals the IEEE quotient (wave-uniform)
 };
 // utils_quant.py:116-124,:144: alpha = max - min ; beta = min ; a = alpha + 1e-8
 template <int DT> __device__ __forceinline__ AsymRow asym_row(float mx, float mn, AsymConst k) {
@@ -243,7 +255,8 @@ template <int DT> __device__ __forceinline__ AsymRow asym_row(float mx, float mn
     r.mn = mn;
     r.al = T::rb(mx - mn);
     r.a = T::rb(r.al + k.c8);
-    r.ra = 1.0f / r.a;  // only used by the bf16 FAST path
+    r.ra = 1.0f / r.a;  // bf16 FAST path: plain multiply; otherwise div_exact()
+    r.mk = div_exact_ok(r.a);
     return r;
 }
 
@@ -270,7 +283,11 @@ template <int DT, bool FAST> __device__ __forceinline__ uint32_t sym_chain(float
         for (int e = 0; e < T::EPD; ++e) idx[e] = idx_i32(f[e]);
     }
 #pragma unroll
-    for (int e = 0; e < T::EPD; ++e) f[e] = FAST ? f[e] * r.rinv : f[e] / r.t2;
+    for (int e = 0; e < T::EPD; ++e) {
+        if constexpr (FAST) f[e] = f[e] * r.rinv;
+        else if constexpr (DT == F16) f[e] = r.mk ? div_exact(f[e], r.t2, r.rinv) : f[e] / r.t2;  // same bits, a third of the ops
+        else f[e] = f[e] / r.t2;  // fp32 rows: the kernel is HBM-bound with the IEEE sequence as well
+    }
     return T::pack(f);
 }
 
@@ -292,7 +309,8 @@ __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const As
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] - r.mn;  // input - beta
     T::round_dt(f);
 #pragma unroll
-    for (int e = 0; e < T::EPD; ++e) f[e] = FAST ? f[e] * r.ra : f[e] / r.a;  // / (alpha + 1e-8)
+    for (int e = 0; e < T::EPD; ++e)  // / (alpha + 1e-8)
+        f[e] = FAST ? f[e] * r.ra : (r.mk ? div_exact(f[e], r.a, r.ra) : f[e] / r.a);
     T::round_dt(f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * k.S;  // * s
@@ -304,7 +322,8 @@ __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const As
         for (int e = 0; e < T::EPD; ++e) idx[e] = idx_i32(f[e]);
     }
 #pragma unroll
-    for (int e = 0; e < T::EPD; ++e) f[e] = (FAST || k.mul_inv) ? f[e] * k.invS : f[e] / k.S;  // .div(s)
+    for (int e = 0; e < T::EPD; ++e)  // .div(s): S = 2^bits - 1 in [3, 2^31], integer numerators: always inside div_exact()'s range
+        f[e] = (FAST || k.mul_inv) ? f[e] * k.invS : div_exact(f[e], k.S, k.invS);
     T::round_dt(f);
 #pragma unroll
     for (int e = 0; e < T::EPD; ++e) f[e] = f[e] * r.a;  // * (alpha + 1e-8)

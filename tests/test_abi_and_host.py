@@ -132,3 +132,14 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle[/.]", r"libfq_oracle", r"\bfqo_"):
                     assert not re.search(pat, src), (os.path.join(dirpath, f), pat)
+
+
+def test_reciprocal_multiply_with_correction_equals_ieee_division(tmp_path):
+    """The kernels replace per-row IEEE divisions (fp16 chains, AsymQuantizer, the autocast path) by a reciprocal
+    multiply + Markstein correction (fq_device.h: div_exact).  tests/c_host/markstein_check.c replays that sequence on
+    the host CPU against `/` over 1e8 quotients spanning the ranges the kernels admit: zero mismatches."""
+    import subprocess
+    exe = str(tmp_path / "markstein_check")
+    subprocess.run(["gcc", "-O2", "-mfma", "-o", exe, os.path.join(ROOT, "tests", "c_host", "markstein_check.c"), "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout[-2000:]

@@ -27,8 +27,8 @@ def main():
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     out = []
-    for dtype, code, esz in ((torch.bfloat16, _lib.DTYPE_BF16, 2), (torch.float32, _lib.DTYPE_F32, 4)):
-        for label, rows, cols, bits, style in SHAPES:
+    for dtype, code, esz in ((torch.bfloat16, _lib.DTYPE_BF16, 2), (torch.float32, _lib.DTYPE_F32, 4), (torch.float16, _lib.DTYPE_F16, 2)):
+        for label, rows, cols, bits, style in (SHAPES if dtype != torch.float16 else SHAPES[:6]):
             n = rows * cols
             nsets = max(2, min(8, int(600e6 // (n * esz * 4)) + 1))   # > 256 MiB of distinct buffers when possible
             g = torch.Generator(device=dev).manual_seed(1)

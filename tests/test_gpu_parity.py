@@ -403,7 +403,12 @@ def test_randomized_stress_all_paths(ops):
             rows, cols = int(rng.integers(1, 40)), int(rng.choice(col_choices))
             bits = int(rng.choice([2, 3, 4, 6, 8, 12, 16])) if kind == "sym" else int(rng.choice([1, 2, 4, 8, 16]))
             layerwise = bool(rng.random() < 0.15)
-            x = rng.standard_normal((rows, cols)).astype(np.float32) * rng.choice([1e-4, 0.02, 1.0, 3.0, 100.0], size=(rows, 1)).astype(np.float32)
+            scales = [1e-4, 0.02, 1.0, 3.0, 100.0]
+            if rng.random() < 0.25:   # row magnitudes at the ends of the dtype's range (denormal scales, overflowing alpha, div_exact's guards)
+                scales = {"fp32": [1e-42, 1e-38, 1e-30, 1e-19, 1e-10, 1e10, 1e19, 1e30, 1e38], "bf16": [1e-38, 1e-30, 1e-19, 1e-10, 1e10, 1e19, 1e30, 1e38],
+                          "fp16": [1e-7, 1e-6, 1e-5, 1e-3, 30.0, 1e3, 2e4, 6e4]}[dtype]
+            with np.errstate(over="ignore"):   # 3e38-scaled rows may overflow to inf: wanted
+                x = rng.standard_normal((rows, cols)).astype(np.float32) * rng.choice(scales, size=(rows, 1)).astype(np.float32)
             if rng.random() < 0.3:
                 x[rng.integers(0, rows), rng.integers(0, cols)] = rng.choice([np.nan, np.inf, -np.inf])
             if rng.random() < 0.3:

@@ -351,6 +351,36 @@ def test_full_size_properties(ops, shape, bits, style):
     assert torch.equal(ops.ste_backward_mask(gg, -2.0, 2.0, b3, m3, shape[0], shape[1]), ref)
 
 
+@pytest.mark.parametrize("shape,bits", [((2048, 4096), 4), ((2048, 5120), 8), ((4096, 11008), 8)])
+def test_full_size_autocast_properties(ops, shape, bits):
+    """The autocast (fp32-arithmetic) kernels at model sizes: narrow result == fp32 result rounded once; the K/V pair
+    launch == two single launches; the fp32-gradient mask backward == where(clipped, 0, round(g)); oracle on sampled rows."""
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    k = torch.randn(shape, generator=g, device="cuda")
+    k[torch.rand(shape, generator=g, device="cuda") < 1e-3] *= 20.0
+    k = k.bfloat16()
+    v = (torch.randn(shape, generator=g, device="cuda") * 0.7).bfloat16()
+    yw, side, rows, cols, got = ops.sym_forward_autocast(k, bits, False, wide=True, train="mask")
+    assert got == "mask" and yw.dtype == torch.float32
+    yn, _, _, _, _ = ops.sym_forward_autocast(k, bits, False, wide=False)
+    assert torch.equal(yn, yw.to(torch.bfloat16))
+    sel = sorted(set([0, shape[0] - 1] + torch.randint(0, shape[0], (30,), generator=torch.Generator().manual_seed(2)).tolist()))
+    yo, _ = O.sym_fwd_autocast(np_from(k[sel]), len(sel), shape[1], bits, "bf16", wide=True)
+    assert bits_equal(np_from(yw[sel]).reshape(yo.shape), yo, "fp32")
+    g32 = torch.randn(shape, generator=g, device="cuda") * 1e-3
+    ref = torch.where((k >= 2.0) | (k <= -2.0), torch.zeros((), device="cuda", dtype=torch.bfloat16), g32.to(torch.bfloat16))
+    gx = ops.train_backward_wide(g32, side, rows, cols, -2.0, 2.0, torch.bfloat16)
+    assert torch.equal(gx, ref) and int((ref == 0).sum()) > 0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        res = ops.pair_forward(k, v, bits, bits, -2.0, 2.0, True, True, wide=True)
+        vw = ops.sym_forward_autocast(v, bits, False, wide=True)[0]
+    assert res is not None and torch.equal(res[0], yw) and torch.equal(res[1], vw)
+    gv = torch.randn(shape, generator=g, device="cuda") * 1e-3
+    ok, ov = ops.pair_backward_wide(g32, gv, res[2], res[3], res[4], res[5], res[6], -2.0, 2.0, torch.bfloat16)
+    assert torch.equal(ok, ref)
+    assert torch.equal(ov, torch.where((v >= 2.0) | (v <= -2.0), torch.zeros((), device="cuda", dtype=torch.bfloat16), gv.to(torch.bfloat16)))
+
+
 # ------------------------------------------------------------------------------------------
 # device-eager semantics: the kernels with sem=DEVICE_EAGER against LIVE ATen ops on this GPU
 # ------------------------------------------------------------------------------------------

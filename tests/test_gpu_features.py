@@ -444,3 +444,39 @@ def test_kv_hooks_in_one_launch(pkg, dtype, autocast):
         kq, vq = quantize_kv(k0, v0, clip, clip, 4)
         k2, v2 = quantize_kv(k0, v0, clip, torch.tensor([-1.0, 1.0]), 4)
     assert torch.equal(kq, out[False][0]) and torch.equal(vq, out[False][1]) and torch.equal(k2, kq) and torch.equal(v2, vq)
+
+
+def test_ddp_wrapped_model_step_is_unchanged(pkg):
+    """BASELINE config 5 runs the kernels per GPU inside the unchanged outer DDP loop (utils/kd_trainer.py:257-277).
+    One rank over RCCL: a DDP-wrapped harness model (bf16 autocast, drop-in quantizers, activation sharing + paired
+    launches on) produces the same loss and gradients as the bare model -- the autograd nodes coexist with DDP's
+    gradient hooks and buckets."""
+    import socket
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ids = TL.deterministic_batch().cuda()
+        bare = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+        wrapped = DDP(TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda(), device_ids=[0])
+        outs = []
+        for m in (bare, wrapped):
+            for _ in range(2):   # second step: DDP has rebuilt its buckets
+                m.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss, logits = m(ids, labels=ids)
+                loss.backward()
+            outs.append((loss.detach(), logits.detach()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for (n, p), (_, q) in zip(bare.named_parameters(), wrapped.module.named_parameters()):
+            assert torch.equal(p.grad, q.grad), n
+    finally:
+        dist.destroy_process_group()

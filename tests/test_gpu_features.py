@@ -446,23 +446,72 @@ def test_kv_hooks_in_one_launch(pkg, dtype, autocast):
     assert torch.equal(kq, out[False][0]) and torch.equal(vq, out[False][1]) and torch.equal(k2, kq) and torch.equal(v2, vq)
 
 
-def test_ddp_wrapped_model_step_is_unchanged(pkg):
-    """BASELINE config 5 runs the kernels per GPU inside the unchanged outer DDP loop (utils/kd_trainer.py:257-277).
-    One rank over RCCL: a DDP-wrapped harness model (bf16 autocast, drop-in quantizers, activation sharing + paired
-    launches on) produces the same loss and gradients as the bare model -- the autograd nodes coexist with DDP's
-    gradient hooks and buckets."""
+def _one_rank_group():
     import socket
 
     import torch.distributed as dist
-    from torch.nn.parallel import DistributedDataParallel as DDP
-    import tiny_llama as TL
-    import llm_qat_amd.utils_quant as UQ
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    return dist
+
+
+@pytest.mark.parametrize("wcache", [False, True])
+def test_fsdp_wrapped_model_step_is_unchanged(pkg, wcache):
+    """run_train.sh trains with `--fsdp "full_shard auto_wrap"` around each decoder layer (+ activation checkpointing):
+    every weight the quantizers see is a view into FSDP's flat parameter, re-pointed before each forward/backward.
+    One rank over RCCL: loss and gradients equal the bare model's, with and without the weight-quant cache."""
+    import functools
+
+    from torch.distributed.fsdp import FullyShardedDataParallel as FSDP
+    from torch.distributed.fsdp.wrap import transformer_auto_wrap_policy
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    dist = _one_rank_group()
+    try:
+        ids = TL.deterministic_batch().cuda()
+
+        def step(model):
+            for _ in range(2):
+                model.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss, logits = model(ids, labels=ids)
+                loss.backward()
+            return loss.detach(), logits.detach()
+
+        bare = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+        inner = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+        wrapped = FSDP(inner, auto_wrap_policy=functools.partial(transformer_auto_wrap_policy, transformer_layer_cls={TL.Layer}),
+                       device_id=0, use_orig_params=True)
+        pkg.enable_weight_quant_cache(wcache)
+        try:
+            l0, g0 = step(bare)
+            l1, g1 = step(wrapped)
+        finally:
+            pkg.enable_weight_quant_cache(False)
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
+        with FSDP.summon_full_params(wrapped, with_grads=True):
+            got = {n.replace("_fsdp_wrapped_module.", ""): p.grad.clone() for n, p in wrapped.named_parameters() if p.grad is not None}
+        want = dict((n, p.grad) for n, p in bare.named_parameters())
+        assert set(got) == set(want), sorted(set(want) ^ set(got))[:5]
+        for n in want:
+            assert torch.equal(got[n].view_as(want[n]), want[n]), n
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_wrapped_model_step_is_unchanged(pkg):
+    """BASELINE config 5 runs the kernels per GPU inside the unchanged outer DDP loop (utils/kd_trainer.py:257-277).
+    One rank over RCCL: a DDP-wrapped harness model (bf16 autocast, drop-in quantizers, activation sharing + paired
+    launches on) produces the same loss and gradients as the bare model -- the autograd nodes coexist with DDP's
+    gradient hooks and buckets."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    dist = _one_rank_group()
     try:
         ids = TL.deterministic_batch().cuda()
         bare = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()

@@ -18,7 +18,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import compiled, ops
 
 # How the backward learns which gradients to zero (results are identical in all three modes):
 #   "mask"   (default) the forward records per-row value bounds + a 1-bit/element STE mask for rows
@@ -72,6 +72,10 @@ class _FakeQuantFunction(torch.autograd.Function):
 
     @staticmethod
     def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False):
+        if torch.compiler.is_compiling():  # Dynamo traces forward/backward of the Function: same kernels as custom ops (compiled.py)
+            ctx.save_for_backward(input, clip_val)
+            ctx.fq_mode = "compiled"
+            return compiled.fake_quant(kind, input, clip_val, num_bits, layerwise, narrow)
         ctx.grad_dtype = None
         if kind == "sym" and ops.autocast_active(input):
             return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
@@ -98,6 +102,9 @@ class _FakeQuantFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        if ctx.fq_mode == "compiled":
+            input, clip_val = ctx.saved_tensors
+            return compiled.fake_quant_bwd(grad_output, input, clip_val), None, None, None
         _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
             lo, hi = ctx.clip
@@ -288,6 +295,8 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
     length, same launch shape).  Results and gradients are bit-identical to the two calls; under autocast both come
     back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served."""
     k, v = key_states, value_states
+    if torch.compiler.is_compiling():
+        return (compiled.fake_quant("sym", k, clip_val_k, num_bits, False), compiled.fake_quant("sym", v, clip_val_v, num_bits, False))
     lo, hi = _clip_pair(clip_val_k)
     if (_PAIR and _BACKWARD_MODE == "mask" and k.is_cuda and _clip_pair(clip_val_v) == (lo, hi) and 2 <= num_bits < 32
             and k.dim() <= 3 and v.dim() <= 3):
@@ -335,6 +344,7 @@ class QuantizeLinear(nn.Linear):
         self.weight_layerwise = weight_layerwise
         if 2 < self.a_bits < 32:
             self.act_quantizer = SymQuantizer if symmetric else AsymQuantizer
+        self._act_kind = "sym" if symmetric else "asym"  # what torch.compile's trace reads (a class identity test does not trace)
 
     def _low_bit_weight(self, w):
         """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding, identity
@@ -403,8 +413,28 @@ class QuantizeLinear(nn.Linear):
             _act_store(key, input_, xq)
         return wq, xq
 
+    def _forward_compiled(self, input_):
+        """forward while torch.compile traces: the same kernels as custom ops, no Python-side caches (compiled.py)"""
+        if self.w_bits >= 32:
+            weight = self.weight
+        elif self.w_bits >= 3:
+            weight = compiled.fake_quant("sym", self.weight, _CLIP, self.w_bits, self.weight_layerwise, narrow=True)
+        else:
+            with torch.no_grad():
+                absmean = self.weight.abs().mean() if self.weight_layerwise else self.weight.abs().mean(dim=1, keepdim=True)
+                sc = absmean if self.w_bits == 1 else 2 * absmean
+            weight = compiled.low_bit_weight_op(self.weight, sc, self.w_bits)
+        if 2 < self.a_bits < 32:
+            input_ = compiled.fake_quant(self._act_kind, input_, _CLIP, self.a_bits, self.act_layerwise, narrow=True)
+        out = nn.functional.linear(input_, weight)
+        if self.bias is not None:
+            out += self.bias.view(1, -1).expand_as(out)
+        return out
+
     def forward(self, input_):
         assert len(self.weight.size()) == 2
+        if torch.compiler.is_compiling():
+            return self._forward_compiled(input_)
         pair = self._pair_forward(input_)
         if pair is not None:
             return nn.functional.linear(pair[1], pair[0])

@@ -529,3 +529,55 @@ def test_ddp_wrapped_model_step_is_unchanged(pkg):
             assert torch.equal(p.grad, q.grad), n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_torch_compile_traces_through_the_quantizers(pkg, autocast):
+    """HF's `--torch_compile` (utils/kd_trainer.py:281-286): while Dynamo traces, the quantizers are torch.library
+    custom ops (llm_qat_amd/compiled.py) -- a QuantizeLinear and a whole harness model compile into ONE graph with no
+    graph break, and (backend aot_eager: same ATen kernels around them) give the eager results bit for bit."""
+    import torch._dynamo as dynamo
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    dynamo.reset()
+    torch.manual_seed(0)
+    for w_bits, a_bits, sym in ((4, 8, True), (8, 8, False), (2, 8, True), (1, 32, True)):
+        lin = UQ.QuantizeLinear(512, 256, symmetric=sym, w_bits=w_bits, a_bits=a_bits).cuda().bfloat16()
+        x = (torch.randn(8, 512, device="cuda") * 1.5).bfloat16().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            ref = lin(x)
+        ref.float().square().mean().backward()
+        gw, gx = lin.weight.grad.clone(), x.grad.clone()
+        lin.zero_grad(set_to_none=True)
+        x.grad = None
+        exp = dynamo.explain(lin)(x)
+        assert exp.graph_count == 1 and exp.graph_break_count == 0, (w_bits, a_bits, sym, [str(r.reason)[:120] for r in exp.break_reasons])
+        clin = torch.compile(lin, backend="aot_eager", fullgraph=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = clin(x)
+        out.float().square().mean().backward()
+        tag = f"w{w_bits} a{a_bits} sym={sym} autocast={autocast}"
+        assert torch.equal(out, ref), tag
+        assert torch.equal(lin.weight.grad, gw) and torch.equal(x.grad, gx), tag
+    # the whole harness model, K/V hooks included (both call-site forms)
+    ids = TL.deterministic_batch().cuda()
+    for kv_one in (False, True):
+        TL.KV_ONE_LAUNCH = kv_one
+        try:
+            model = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                loss, logits = model(ids, labels=ids)
+            loss.backward()
+            want = [p.grad.clone() for p in model.parameters()]
+            model.zero_grad(set_to_none=True)
+            dynamo.reset()
+            cmodel = torch.compile(model, backend="aot_eager", fullgraph=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                closs, clogits = cmodel(ids, labels=ids)
+            closs.backward()
+            assert torch.equal(closs, loss) and torch.equal(clogits, logits), (kv_one, closs.item(), loss.item())
+            for (n, p), w in zip(model.named_parameters(), want):
+                assert torch.equal(p.grad, w), (kv_one, n)
+        finally:
+            TL.KV_ONE_LAUNCH = False
+    dynamo.reset()

@@ -56,9 +56,13 @@ template <int DT, int TPR, bool NTL, bool NTS>
 static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
     const int64_t grid = TPR == 64 ? (a.rows + 3) / 4 : a.rows;
     constexpr int BLOCK = TPR == 64 ? 256 : TPR;
+    const bool mask = a.mask || a.mask1;  // the mask-recording code lives in its own instantiation (it costs the plain one 7 %)
     switch (hpt) {
-#define H(N) \
-    case N: FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS>), grid, BLOCK, st, a); break;
+#define H(N)                                                                                            \
+    case N:                                                                                             \
+        if (mask) FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, true>), grid, BLOCK, st, a);     \
+        else FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, false>), grid, BLOCK, st, a);         \
+        break;
         H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(8)
 #undef H
         default: break;

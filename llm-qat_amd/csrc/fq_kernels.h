@@ -280,7 +280,7 @@ template <bool NT> __device__ __forceinline__ void st8(uint2* p, uint2 v) {
     }
 }
 
-template <int DT, int TPR, int HPT, bool NTL, bool NTS>
+template <int DT, int TPR, int HPT, bool NTL, bool NTS, bool MASK>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(RowArgs a) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "16-bit input, fp32 output");
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
         bnd[2 * row] = m;
         bnd[2 * row + 1] = -m;
     }
-    const bool want_mask = msk && !((m < a.hi) && (-m > a.lo));  // wave-uniform; NaN row: mask written, all bits 0
+    const bool want_mask = MASK && msk && !((m < a.hi) && (-m > a.lo));  // wave-uniform; NaN row: mask written, all bits 0
     const bool sym_clip = a.lo == -a.hi;
     uint64_t* mrow = msk + row * a.mask_row_words;
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
             T::unpack(r[i].y, f1);
             f[0] = f0[0], f[1] = f0[1], f[2] = f1[0], f[3] = f1[1];
         }
-        if (want_mask && (h - (t & 63) < nh)) {  // wave-uniform: this wave's 64-half-vector group exists
+        if (MASK && want_mask && (h - (t & 63) < nh)) {  // wave-uniform: this wave's 64-half-vector group exists
             const int hc = h < nh ? h : nh - 1;
             uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(hc >> 6) * 4;
             if (sym_clip) ste_mask_store<4, true>(f, a.lo, a.hi, gw, t & 63);

@@ -2,6 +2,7 @@
 // The kernels are instantiated per element type in fq_f32.hip / fq_bf16.hip / fq_f16.hip so the
 // library builds in parallel; fq_api.hip holds the extern "C" entry points.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -25,8 +26,27 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 //    before and still sits in the 256 MiB Infinity Cache, where plain loads are faster (16 MB: 5.9 vs 6.1 us,
 //    45 MB: 14.2 vs 16.1 us, 67 MB: 20.4 vs 22.2 us); the big MLP weights come from HBM, where NT loads are faster
 //    (84 MB: 27.8 vs 28.8 us, 90 MB: 30.3 vs 31.3 us, 113 MB: 37.0 vs 38.0 us).
-constexpr int64_t NT_STORE_MIN_BYTES = 4ll << 20;
-constexpr int64_t NT_LOAD_MIN_BYTES = 72ll << 20;
+// Tuning overrides (read once per process, MiB): LLMQAT_FQ_NT_STORE_MIN_MB / LLMQAT_FQ_NT_LOAD_MIN_MB.  A load threshold
+// below the store threshold is raised to it (the kernels come in three cache-policy flavours: none, stores, both).
+inline int64_t nt_env_mib(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt << 20;
+    const long long mb = atoll(v);
+    return (mb < 0 ? dflt : (int64_t)mb) << 20;
+}
+inline int64_t nt_store_min_bytes() {
+    static const int64_t v = nt_env_mib("LLMQAT_FQ_NT_STORE_MIN_MB", 4);
+    return v;
+}
+inline int64_t nt_load_min_bytes() {
+    static const int64_t v = [] {
+        const int64_t l = nt_env_mib("LLMQAT_FQ_NT_LOAD_MIN_MB", 72), s = nt_store_min_bytes();
+        return l < s ? s : l;
+    }();
+    return v;
+}
+#define NT_STORE_MIN_BYTES (::fq::nt_store_min_bytes())
+#define NT_LOAD_MIN_BYTES (::fq::nt_load_min_bytes())
 
 constexpr int64_t REG_MAX_VEC = 1024 * 8;    // longest row (in 16-byte vectors) the register kernels hold
 constexpr int64_t GENERIC_MAX_COLS = 32768;  // longest row the scalar-load kernel sweeps

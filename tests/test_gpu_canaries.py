@@ -78,6 +78,41 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
                 ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr if mb else None, mb, ws.ptr, wsb, st),
                    "sym_fwd_autocast narrow", allow=(-8,))
                 ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, None, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast narrow plain")
+            if mb:   # two tensors per launch (second tensor: its own guarded buffers, rows2 rows), every flavour
+                rows2 = max(1, rows // 2)
+                n2 = rows2 * cols
+                x2, y2, g2, gx2 = Guarded(n2 * es, off), Guarded(n2 * es, off), Guarded(n2 * es, off), Guarded(n2 * es, off)
+                x2.payload().view(dtype).copy_((torch.randn(n2, generator=g, device="cuda") * 1.5).to(dtype))
+                g2.payload().view(dtype).copy_(torch.randn(n2, generator=g, device="cuda").to(dtype))
+                b2 = Guarded(rows2 * 8)
+                mb2 = L.fq_ste_mask_bytes(rows2, cols, code)
+                m2 = Guarded(mb2)
+                everything += [x2, y2, g2, gx2, b2, m2]
+                rc = L.fq_sym_fwd_pair(x.ptr, y.ptr, rows, 4, bounds.ptr, mask.ptr, mb, x2.ptr, y2.ptr, rows2, 8, b2.ptr, m2.ptr, mb2,
+                                       cols, code, 0, 0, -2.0, 2.0, st)
+                ok(rc, "sym_fwd_pair", allow=(-8,))
+                if rc == 0:
+                    ok(L.fq_ste_bwd_mask_pair(gr.ptr, gx.ptr, rows, bounds.ptr, mask.ptr, g2.ptr, gx2.ptr, rows2, b2.ptr, m2.ptr, cols, -2.0, 2.0, code, st),
+                       "ste_bwd_mask_pair", allow=(-8,))
+                if es == 2:
+                    yw, yw2 = Guarded(n * 4, off * 2), Guarded(n2 * 4, off * 2)
+                    g32, g32b = Guarded(n * 4, off * 2), Guarded(n2 * 4, off * 2)
+                    g32.payload().view(torch.float32).copy_(torch.randn(n, generator=g, device="cuda"))
+                    g32b.payload().view(torch.float32).copy_(torch.randn(n2, generator=g, device="cuda"))
+                    everything += [yw, yw2, g32, g32b]
+                    ok(L.fq_sym_fwd_pair(x.ptr, y.ptr, rows, 4, bounds.ptr, mask.ptr, mb, x2.ptr, y2.ptr, rows2, 8, b2.ptr, m2.ptr, mb2,
+                                         cols, code, 0, 1, -2.0, 2.0, st), "sym_fwd_pair autocast narrow", allow=(-8,))
+                    rc = L.fq_sym_fwd_pair(x.ptr, yw.ptr, rows, 4, bounds.ptr, mask.ptr, mb, x2.ptr, yw2.ptr, rows2, 8, b2.ptr, m2.ptr, mb2,
+                                           cols, code, 0, 2, -2.0, 2.0, st)
+                    ok(rc, "sym_fwd_pair autocast wide", allow=(-8,))
+                    if rc == 0:
+                        ok(L.fq_ste_bwd_mask_wide(g32.ptr, gx.ptr, rows, bounds.ptr, mask.ptr, g32b.ptr, gx2.ptr, rows2, b2.ptr, m2.ptr,
+                                                  cols, -2.0, 2.0, code, st), "ste_bwd_mask_wide pair", allow=(-8,))
+                    rc = L.fq_sym_fwd_autocast(x.ptr, yw.ptr, rows, cols, 8, code, 1, -2.0, 2.0, bounds.ptr, mask.ptr, mb, ws.ptr, wsb, st)
+                    ok(rc, "sym_fwd_autocast wide + mask", allow=(-8,))
+                    if rc == 0:
+                        ok(L.fq_ste_bwd_mask_wide(g32.ptr, gx.ptr, rows, bounds.ptr, mask.ptr, None, None, 0, None, None, cols, -2.0, 2.0, code, st),
+                           "ste_bwd_mask_wide", allow=(-8,))
             sc = Guarded(rows * es)
             sc.payload().view(dtype).fill_(0.05)
             everything.append(sc)

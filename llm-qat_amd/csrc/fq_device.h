@@ -181,6 +181,32 @@ template <class Op, int NW> __device__ __forceinline__ uint32_t block_reduce(uin
     return r;
 }
 
+// three reductions behind ONE barrier (AsymQuantizer: NaN detector, max, min); lds is [3][NW]
+template <class Op0, class Op1, class Op2, int NW>
+__device__ __forceinline__ void block_reduce3(uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t (*lds)[NW > 1 ? NW : 1]) {
+    v0 = wave_reduce<Op0>(v0);
+    v1 = wave_reduce<Op1>(v1);
+    v2 = wave_reduce<Op2>(v2);
+    if constexpr (NW > 1) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            lds[0][wave] = v0;
+            lds[1][wave] = v1;
+            lds[2][wave] = v2;
+        }
+        __syncthreads();
+        v0 = lds[0][0];
+        v1 = lds[1][0];
+        v2 = lds[2][0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) {
+            v0 = Op0::f(v0, lds[0][i]);
+            v1 = Op1::f(v1, lds[1][i]);
+            v2 = Op2::f(v2, lds[2][i]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // per-row scale terms
 // ------------------------------------------------------------------------------------

@@ -172,9 +172,9 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             minmax_acc<DT>(mm, r[i].z);
             minmax_acc<DT>(mm, r[i].w);
         }
-        const uint32_t nb = block_reduce<OpMaxU, NW>(T::absmax_finish(mm.absacc), red[0]);
-        float mx = as_f(block_reduce<OpMaxF, NW>(as_u(mm.mx), red[1]));
-        float mn = as_f(block_reduce<OpMinF, NW>(as_u(mm.mn), red[2]));
+        uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
+        block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
+        float mx = as_f(umx), mn = as_f(umn);
         if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
         ar = asym_row<DT>(mx, mn, a.asym);
         ub = mx;

@@ -74,7 +74,21 @@ class _DeviceOf:
 
 
 def _stream(x):
-    return torch.cuda.current_stream(x.device).cuda_stream
+    idx = x.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return torch.cuda.current_stream().cuda_stream  # the argument-free form is several us cheaper
+    return torch.cuda.current_stream(idx).cuda_stream
+
+
+_ws_bytes_memo = {}
+
+
+def _ws_bytes(rows, cols, code):
+    k = (rows, cols, code)
+    v = _ws_bytes_memo.get(k)
+    if v is None:
+        v = _ws_bytes_memo[k] = _lib.lib().fq_rowwise_workspace_bytes(rows, cols, code)
+    return v
 
 
 def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
@@ -90,7 +104,7 @@ def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(xc)
     L = _lib.lib()
-    ws_bytes = L.fq_rowwise_workspace_bytes(rows, cols, code)
+    ws_bytes = _ws_bytes(rows, cols, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     ws_ptr = ws.data_ptr() if ws is not None else None
     bounds = idx = scale = None
@@ -223,7 +237,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     y = torch.empty(xc.shape, dtype=torch.float32 if wide else x.dtype, device=x.device)
     L = _lib.lib()
     side, got = None, None
-    ws_bytes = L.fq_rowwise_workspace_bytes(rows, cols, code)
+    ws_bytes = _ws_bytes(rows, cols, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     ws_ptr = ws.data_ptr() if ws is not None else None
     with _DeviceOf(x):

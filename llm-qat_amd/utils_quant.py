@@ -55,7 +55,7 @@ class _FakeQuantFunction(torch.autograd.Function):
     def _fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow):
         """The reference under torch.autocast("cuda"): fp32 arithmetic behind the reciprocal, fp32 result (or, for
         QuantizeLinear's own operands, that result rounded once -- exactly what F.linear's autocast cast does next)."""
-        mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
+        mode = _BACKWARD_MODE
         lo, hi = _clip_pair(clip_val)
         out, side, rows, cols, got = ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow, lo=lo, hi=hi,
                                                               train=None if mode == "plain" else mode)
@@ -77,9 +77,14 @@ class _FakeQuantFunction(torch.autograd.Function):
             ctx.fq_mode = "compiled"
             return compiled.fake_quant(kind, input, clip_val, num_bits, layerwise, narrow)
         ctx.grad_dtype = None
+        if not ctx.needs_input_grad[0]:  # no backward will run (eval, frozen input): nothing to record or save
+            ctx.fq_mode = "none"
+            if kind == "sym" and ops.autocast_active(input):
+                return ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow)[0]
+            return ops.sym_quantize(input, num_bits, layerwise) if kind == "sym" else ops.asym_quantize(input, num_bits, layerwise)
         if kind == "sym" and ops.autocast_active(input):
             return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
-        mode = _BACKWARD_MODE if ctx.needs_input_grad[0] else "plain"
+        mode = _BACKWARD_MODE
         ctx.fq_mode = "plain"
         ctx.row_bounds = None
         if mode == "mask":

@@ -31,13 +31,16 @@ for name, fn in (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, cli
                  ("autograd.backward over 64 nodes (/64)", many_backward),
                  ("eager chain fwd (grad)", lambda: EagerSym.apply(xg, clip, 8, False)),
                  ("eager chain fwd+bwd", lambda: EagerSym.apply(xg, clip, 8, False).backward(g))):
-    for _ in range(50):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(N):
-        fn()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    per = 1e6 * (t1 - t0) / N / (64 if "64 nodes" in name else 1)
+    best = float("inf")
+    for rep in range(3):   # best of three: the first loop of a process runs ~2x slow (measured), whatever it times
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(N):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        best = min(best, t1 - t0)
+    per = 1e6 * best / N / (64 if "64 nodes" in name else 1)
     print(f"{name:40s} {per:7.1f} us/call (host)")

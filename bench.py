@@ -484,6 +484,12 @@ def main():
                                 "what": "both launches of one step: 10 algorithmic B/elem / sum of launch times"}
         out["unpaired_step"] = {"ms_per_step": round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
                                 "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2)"}
+        # a live yardstick for "how fast can this device move the same bytes": ATen's device-to-device copy of the W tensor
+        # (read 90.2 MB + write 90.2 MB = one single-tensor forward's algorithmic bytes), timed like the kernels above
+        cmean, cpct = wl.time_kernel(lambda s: s["yw"].copy_(s["w"]), it)
+        out["copy_reference"] = {"what": "torch Tensor.copy_ device-to-device over the same 180.4 MB as sym_fwd_w4 (compare kernels[0])",
+                                 "us_per_launch": round(cmean * 1e3, 2), "gbs": round(nb * FWD_BYTES_PER_ELEM / (cmean * 1e-3) / 1e9, 1),
+                                 "us_p10_p50_p90": [round(v * 1e3, 2) for v in cpct]}
         if world == 1:
             out["gpu_eager"] = gpu_eager(wl)
             out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)

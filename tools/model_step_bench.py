@@ -92,9 +92,13 @@ def main():
                 else:
                     model = build(quant, args.layers, wb, ab, kvb)
                 llm_qat_amd.enable_weight_quant_cache(wcache)
+                torch.cuda.reset_peak_memory_stats()
+                base = torch.cuda.memory_allocated()   # parameters (+ ids): the step's own peak is reported on top of this
                 ms = timed(lambda: step(model, ids, ckpt), args.iters)
+                peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
                 llm_qat_amd.enable_weight_quant_cache(False)
-                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers))
+                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers,
+                                 step_peak_gib_above_params=round(peak, 2)))
                 print(rows[-1], flush=True)
                 del model
                 torch.cuda.empty_cache()

@@ -715,3 +715,35 @@ def test_wide_result_mask_path_vs_oracle(ops, dtype):
     s, mb = side(2, 40000)
     rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), 2, 40000, 8, code, 1, -2.0, 2.0, s.data_ptr(), s.data_ptr() + 16, mb, None, 0, st)
     assert rc == _lib.ERR_UNSUPPORTED
+
+
+def test_tensors_beyond_2_31_elements(ops):
+    """64-bit indexing everywhere: a layerwise row of 2^31 + 4096 elements (two-pass kernels, plain STE) and a row-wise
+    tensor of 2.1e9 elements (register kernels + mask backward), against ATen on the same GPU."""
+    import llm_qat_amd
+    from oracle import eager_chain as E
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(0)
+        n = 2 ** 31 + 4096
+        x = torch.randn(n, generator=g, device="cuda", dtype=torch.bfloat16)
+        x[n - 5] = 7.5   # the global max sits beyond the 2^31 boundary
+        y = ops.sym_quantize(x, 8, True)
+        assert torch.equal(y, E.sym_forward(x, 8, layerwise=True)) and float(y[n - 5]) > 7.0
+        del y
+        gr = torch.randn(n, generator=g, device="cuda", dtype=torch.bfloat16)
+        assert torch.equal(ops.ste_backward(gr, x, -2.0, 2.0), torch.where((x >= 2.0) | (x <= -2.0), torch.zeros_like(gr), gr))
+        del x, gr
+        torch.cuda.empty_cache()
+        rows, cols = 2 ** 20 + 3, 2048 + 8
+        x = torch.randn(rows, cols, generator=g, device="cuda", dtype=torch.bfloat16)
+        y, bounds, mask = ops.quantize_train("sym", x, 4, False, -2.0, 2.0)
+        sel = torch.tensor([0, 1, rows // 2, rows - 2, rows - 1], device="cuda")
+        assert torch.equal(y[sel], E.sym_forward(x[sel], 4))
+        del y
+        gr = torch.randn(rows, cols, generator=g, device="cuda", dtype=torch.bfloat16)
+        gx = ops.ste_backward_mask(gr, -2.0, 2.0, bounds, mask, rows, cols)
+        assert torch.equal(gx, torch.where((x >= 2.0) | (x <= -2.0), torch.zeros_like(gr), gr))
+    finally:
+        llm_qat_amd.set_semantics("cpu_eager")
+        torch.cuda.empty_cache()

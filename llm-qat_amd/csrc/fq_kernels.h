@@ -62,6 +62,32 @@ __device__ __forceinline__ void ste_mask_store(const float (&f)[N], float lo, fl
     }
     if (lane < N) gw[lane] = mine;
 }
+// 64-bit value of lane `l` (compile-time constant) as a wave-uniform scalar
+template <int L> __device__ __forceinline__ uint64_t readlane64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, L);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), L);
+    return ((uint64_t)hi << 32) | lo;
+}
+// The mask words of ALL of a wave's slots in one 8-byte vector load per lane, issued next to the gradient loads:
+// lane l holds word (l % WPG) of slot (l / WPG)'s group (WPG = words per group).  Fetching them slot by slot instead
+// puts a dependent memory round trip in front of every store (the compiler turns those wave-uniform loads into
+// VMEM loads + v_readfirstlane, serialised by vmcnt behind everything issued before them).
+template <int WPG, int SLOTS, int STRIDE>
+__device__ __forceinline__ uint64_t ste_mask_prefetch(const uint64_t* mrow, int64_t first, int t, int n) {
+    static_assert(SLOTS * WPG <= 64, "one word per lane");
+    const int lane = t & 63, slot = lane / WPG, e = lane % WPG;
+    if (slot >= SLOTS) return 0;
+    int v = (t - lane) + slot * STRIDE;  // the wave's first vector of that slot
+    v = v < n ? v : n - 1;
+    return mrow[((first + v) >> 6) * WPG + e];
+}
+template <int WPG, int I, int E = 0> __device__ __forceinline__ void ste_mask_words(uint64_t held, uint64_t (&mw)[WPG]) {
+    if constexpr (E < WPG) {
+        mw[E] = readlane64<I * WPG + E>(held);
+        ste_mask_words<WPG, I, E + 1>(held, mw);
+    }
+}
+
 // apply group mask words (wave-uniform, in SGPRs) to this lane's gradient vector.  inverse_ballot turns a 64-bit
 // wave mask straight into a per-lane predicate, so each half-dword costs one v_cndmask with the SGPR pair as the
 // selector (and gfx950's v_bitop3 folds the two ANDs): 3 VALU ops per dword instead of a shift/and/compare chain.
@@ -791,6 +817,37 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
 // clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
 // every wave covers exactly one mask group per slot.
+template <int DT, int VPT, bool NTS, int I = 0>
+__device__ __forceinline__ void ste_mask_slots(const uint4 (&rg)[VPT], uint64_t held, uint4* out, int t, int nvec) {
+    if constexpr (I < VPT) {
+        constexpr int EPV = 16 / Ty<DT>::ESIZE;
+        uint64_t mw[EPV];
+        ste_mask_words<EPV, I>(held, mw);
+        const int v = t + I * STE_THREADS;
+        const uint4 o = ste_mask_apply<DT>(rg[I], mw);
+        if (v < nvec) st16<NTS>(&out[v], o);
+        ste_mask_slots<DT, VPT, NTS, I + 1>(rg, held, out, t, nvec);
+    }
+}
+
+template <int DT, int HPT, bool NTS, int I = 0>
+__device__ __forceinline__ void ste_mask_wide_slots(const uint4 (&rg)[HPT], uint64_t held, uint2* out, int t, int nh) {
+    if constexpr (I < HPT) {
+        using T = Ty<DT>;
+        uint64_t mw[4];
+        ste_mask_words<4, I>(held, mw);
+        const int h = t + I * STE_THREADS;
+        const float f0[2] = {as_f(rg[I].x), as_f(rg[I].y)}, f1[2] = {as_f(rg[I].z), as_f(rg[I].w)};
+        uint32_t w0 = T::pack(f0), w1 = T::pack(f1);
+        w0 &= (__builtin_amdgcn_inverse_ballot_w64(mw[0]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
+              (__builtin_amdgcn_inverse_ballot_w64(mw[1]) ? 0x0000FFFFu : 0xFFFFFFFFu);
+        w1 &= (__builtin_amdgcn_inverse_ballot_w64(mw[2]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
+              (__builtin_amdgcn_inverse_ballot_w64(mw[3]) ? 0x0000FFFFu : 0xFFFFFFFFu);
+        if (h < nh) st8<NTS>(&out[h], make_uint2(w0, w1));
+        ste_mask_wide_slots<DT, HPT, NTS, I + 1>(rg, held, out, t, nh);
+    }
+}
+
 struct SteSecond {  // optional second tensor of a mask-backward launch (same dtype and cols; see RowArgs)
     int64_t rows0;
     const void* g;
@@ -837,18 +894,8 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
             if (v < nvec) st16<NTS>(&or_[v], rg[i]);
         }
     } else {
-        const uint64_t* mrow = mask + row * mask_row_words;
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = t + i * STE_THREADS;
-            int vc = v < nvec ? v : nvec - 1;
-            const int64_t grp = __builtin_amdgcn_readfirstlane((int)((vs + vc) >> 6));
-            uint64_t mw[EPV];
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) mw[e] = mrow[grp * EPV + e];  // wave-uniform address -> scalar loads
-            const uint4 o = ste_mask_apply<DT>(rg[i], mw);
-            if (v < nvec) st16<NTS>(&or_[v], o);
-        }
+        const uint64_t held = ste_mask_prefetch<EPV, VPT, STE_THREADS>(mask + row * mask_row_words, vs, t, nvec);
+        ste_mask_slots<DT, VPT, NTS>(rg, held, or_, t, nvec);
     }
 }
 
@@ -887,24 +934,16 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(const void* 
         h = h < nh ? h : nh - 1;
         rg[i] = ld16<NTL>(&gr[h]);
     }
-    const uint64_t* mrow = mask + row * mask_row_words;
+    if (safe) {
 #pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-        const int h = t + i * STE_THREADS;
-        const float f0[2] = {as_f(rg[i].x), as_f(rg[i].y)}, f1[2] = {as_f(rg[i].z), as_f(rg[i].w)};
-        uint32_t w0 = T::pack(f0), w1 = T::pack(f1);
-        if (!safe) {
-            const int hc = h < nh ? h : nh - 1;
-            const int64_t grp = __builtin_amdgcn_readfirstlane((int)((hs + hc) >> 6));
-            uint64_t mw[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mw[e] = mrow[grp * 4 + e];  // wave-uniform address -> scalar loads
-            w0 &= (__builtin_amdgcn_inverse_ballot_w64(mw[0]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
-                  (__builtin_amdgcn_inverse_ballot_w64(mw[1]) ? 0x0000FFFFu : 0xFFFFFFFFu);
-            w1 &= (__builtin_amdgcn_inverse_ballot_w64(mw[2]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
-                  (__builtin_amdgcn_inverse_ballot_w64(mw[3]) ? 0x0000FFFFu : 0xFFFFFFFFu);
+        for (int i = 0; i < HPT; ++i) {
+            const int h = t + i * STE_THREADS;
+            const float f0[2] = {as_f(rg[i].x), as_f(rg[i].y)}, f1[2] = {as_f(rg[i].z), as_f(rg[i].w)};
+            if (h < nh) st8<NTS>(&or_[h], make_uint2(T::pack(f0), T::pack(f1)));
         }
-        if (h < nh) st8<NTS>(&or_[h], make_uint2(w0, w1));
+    } else {
+        const uint64_t held = ste_mask_prefetch<4, HPT, STE_THREADS>(mask + row * mask_row_words, hs, t, nh);
+        ste_mask_wide_slots<DT, HPT, NTS>(rg, held, or_, t, nh);
     }
 }
 

@@ -17,6 +17,7 @@ import weakref
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from . import compiled, ops
 
@@ -106,6 +107,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # the backward launches kernels: a double backward must fail loudly, not return silent zeros
     def backward(ctx, grad_output):
         if ctx.fq_mode == "compiled":
             input, clip_val = ctx.saved_tensors
@@ -272,6 +274,7 @@ class _PairNode(torch.autograd.Function):
         return wq.view_as(wq), xq.view_as(xq)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gw, gx):
         _bwd_epoch[0] += 1
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -329,6 +332,7 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
         return y.view_as(y)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output):
         lo, hi = ctx.clip
         if ctx.ste_mask is not None:

@@ -581,3 +581,18 @@ def test_torch_compile_traces_through_the_quantizers(pkg, autocast):
         finally:
             TL.KV_ONE_LAUNCH = False
     dynamo.reset()
+
+
+def test_double_backward_fails_loudly(pkg):
+    """The reference's backward is built from differentiable ATen ops; this one launches kernels.  Asking for a second
+    derivative through it must raise instead of silently returning nothing."""
+    from llm_qat_amd.utils_quant import SymQuantizer
+    x = torch.randn(8, 256, device="cuda", requires_grad=True)
+    y = SymQuantizer.apply(x, torch.tensor([-2.0, 2.0]), 8, False)
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):   # no graph behind gx (or once_differentiable's error when grad_output itself carries one)
+        gx.sum().backward()
+    g = torch.ones_like(y, requires_grad=True)
+    (gx,) = torch.autograd.grad(y, x, grad_outputs=g, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable"):
+        gx.sum().backward()

@@ -347,17 +347,28 @@ def gpu_eager(wl, iters=5, autocast=False):
     """The reference's eager chain on this GPU: the like-for-like 'before' (14 launches per fwd+bwd).
     autocast=True: inside torch.autocast("cuda", bf16), as LLM-QAT trains (fp32 intermediates behind the reciprocal)."""
     import torch
-    from oracle import eager_chain as E
     clip = torch.tensor([-2.0, 2.0])
-    s = wl.sets[0]
+
+    # the op chain of models/utils_quant.py:53-59,:71-72 (forward) and :83-87 (backward), restated here for the timing
+    # (nothing from oracle/ runs on the GPU legs of the benchmark)
+    def sym_forward(x, bits):
+        top = torch.max(torch.abs(x), dim=-1, keepdim=True)[0].expand_as(x)
+        s = (2 ** (bits - 1) - 1) / (top + 1e-6)
+        return torch.round(x * s).div(s + 1e-6)
+
+    def ste_backward(g, x):
+        gx = g.clone()
+        gx[x.ge(clip[1])] = 0
+        gx[x.le(clip[0])] = 0
+        return gx
 
     def one(k):
         s = wl.sets[k % wl.nsets]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            yw = E.sym_forward(s["w"], 4)
-            ya = E.sym_forward(s["a"], 8)
-        E.ste_backward(s["gw"].to(yw.dtype), s["w"], clip)
-        E.ste_backward(s["ga"].to(ya.dtype), s["a"], clip)
+            yw = sym_forward(s["w"], 4)
+            ya = sym_forward(s["a"], 8)
+        ste_backward(s["gw"].to(yw.dtype), s["w"])
+        ste_backward(s["ga"].to(ya.dtype), s["a"])
 
     one(0)
     torch.cuda.synchronize()
@@ -367,7 +378,7 @@ def gpu_eager(wl, iters=5, autocast=False):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {"value": round(2 * wl.n / dt / 1e9, 2), "unit": "Gelem/s", "ms_per_step": round(dt * 1e3, 3),
-            "what": "oracle/eager_chain.py (the reference's op chain) on the same tensors, same GPU"
+            "what": "the reference's eager op chain (restated in bench.py) on the same tensors, same GPU"
                     + (", inside torch.autocast(cuda, bf16) as LLM-QAT trains (fp32 intermediates, fp32 outputs)" if autocast else "")}
 
 

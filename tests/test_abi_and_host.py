@@ -134,6 +134,27 @@ def test_product_never_imports_the_oracle():
                     assert not re.search(pat, src), (os.path.join(dirpath, f), pat)
 
 
+def test_oracle_is_only_reached_from_the_allowed_places():
+    """Besides tests/: __graft_entry__ (build() compiles it, smoke() checks against it) and bench.py's cpu_baseline leg
+    (cpu_baseline, cpu_c_port, parity_gate) -- nowhere else: no tool, no GPU leg of the benchmark."""
+    import ast
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"cpu_baseline", "cpu_c_port", "parity_gate"}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.ImportFrom) and (sub.module or "").split(".")[0] == "oracle":
+                    assert node.name in allowed, f"bench.py:{node.name} imports oracle"
+                if isinstance(sub, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in sub.names):
+                    assert node.name in allowed, f"bench.py:{node.name} imports oracle"
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any((getattr(n, "module", None) or "").startswith("oracle") or any(a.name.startswith("oracle") for a in n.names) for n in top)
+
+
 def test_reciprocal_multiply_with_correction_equals_ieee_division(tmp_path):
     """The kernels replace per-row IEEE divisions (fp16 chains, AsymQuantizer, the autocast path) by a reciprocal
     multiply + Markstein correction (fq_device.h: div_exact).  tests/c_host/markstein_check.c replays that sequence on

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT)
 import torch
 import llm_qat_amd
 from llm_qat_amd.utils_quant import SymQuantizer
-from oracle.eager_chain import EagerSym
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from tiny_llama import EagerQuant   # test infrastructure: the reference's eager op chain as autograd Functions
+EagerSym = EagerQuant().SymQuantizer
 
 clip = torch.tensor([-2.0, 2.0])
 x = torch.randn(64, 256, device="cuda", dtype=torch.bfloat16)

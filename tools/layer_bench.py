@@ -77,7 +77,9 @@ def main():
     args = ap.parse_args()
     import llm_qat_amd
     from llm_qat_amd.utils_quant import SymQuantizer
-    from oracle.eager_chain import EagerSym
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tiny_llama import EagerQuant   # test infrastructure: the reference's eager op chain as autograd Functions
+    EagerSym = EagerQuant().SymQuantizer
     dev = torch.device("cuda:0")
     h, m = MODELS[args.model]
     W, A = build(h, m, args.seq, dev)

@@ -382,6 +382,21 @@ def gpu_eager(wl, iters=5, autocast=False):
                     + (", inside torch.autocast(cuda, bf16) as LLM-QAT trains (fp32 intermediates, fp32 outputs)" if autocast else "")}
 
 
+def ensure_built(local_rank, dist):
+    """A fresh checkout has no libllmqat_fakequant.so yet: compile it (one rank per node does, the others wait).
+    Building the product is not a fallback -- without the library the benchmark fails loudly."""
+    lib = os.path.join(ROOT, "llm-qat_amd", "libllmqat_fakequant.so")
+    if not os.path.exists(lib) and local_rank == 0:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_fq_build", os.path.join(ROOT, "llm-qat_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        print("bench.py: building the HIP library (first run in this checkout)", file=sys.stderr)
+        mod.build_extension()
+    if dist is not None:
+        dist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -422,6 +437,7 @@ def main():
         print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE unset); running 1 rank",
               file=sys.stderr)
 
+    ensure_built(local_rank, dist)
     wl = Workload(device)
     wl.prime_bounds()
     seconds = timed_region(wl.step, args.steps, args.warmup, torch.cuda.synchronize, dist)

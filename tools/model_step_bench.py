@@ -21,8 +21,13 @@ from torch.utils.checkpoint import checkpoint  # noqa: E402
 import tiny_llama as TL  # noqa: E402
 
 
+DIMS = {"7b": (4096, 11008, 32), "13b": (5120, 13824, 40)}
+MODEL = "7b"
+
+
 def build(quant, layers, wb, ab, kvb):
-    cfg = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=layers, num_attention_heads=32,
+    h, inter, heads = DIMS[MODEL]
+    cfg = dict(vocab_size=32000, hidden_size=h, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
                max_position_embeddings=2048, rms_norm_eps=1e-6)
     torch.manual_seed(0)
     m = TL.TinyLlama(quant, cfg=cfg, w_bits=wb, a_bits=ab, kv_bits=kvb).bfloat16().cuda()
@@ -63,10 +68,12 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--autocast", action="store_true", help="run the step under torch.autocast(cuda, bf16), as run_train.sh does")
+    ap.add_argument("--model", default="7b", choices=sorted(DIMS), help="layer dimensions (LLaMA-7B or LLaMA-13B)")
     ap.add_argument("--only", default=None, help="run only the implementation whose label equals this (for profiling), W4A8KV4, no checkpointing")
     args = ap.parse_args()
-    global AUTOCAST
+    global AUTOCAST, MODEL
     AUTOCAST = args.autocast
+    MODEL = args.model
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
 
@@ -97,14 +104,15 @@ def main():
                 ms = timed(lambda: step(model, ids, ckpt), args.iters)
                 peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
                 llm_qat_amd.enable_weight_quant_cache(False)
-                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers,
+                rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers, dims=MODEL,
                                  step_peak_gib_above_params=round(peak, 2)))
                 print(rows[-1], flush=True)
                 del model
                 torch.cuda.empty_cache()
     if args.only:
         return
-    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "model_step_bench_autocast.json" if AUTOCAST else "model_step_bench.json"), "w"), indent=1)
+    name = "model_step_bench" + ("" if MODEL == "7b" else "_" + MODEL) + ("_autocast" if AUTOCAST else "") + ".json"
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
 
 
 if __name__ == "__main__":

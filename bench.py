@@ -16,10 +16,15 @@ Infinity Cache cannot serve re-reads.  `value` = elements processed per second, 
 
 The op is per-tensor and does not shard ("replicas only"): with --gpus N every rank runs
 the same step on its own GPU, no data-path collective; value = N * per-rank elements / max-over-ranks time.
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, as fresh child processes, BEFORE
+anything touches a GPU; under `python -m torch.distributed.run` it joins the ranks the launcher started.
+A request for N ranks never reports fewer: if a rank is missing the run exits non-zero.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (STE backward): algorithmic bytes / live HIP-event launch time vs 8 TB/s
-  kernels       the same for every kernel of the step
+Extra objects on the JSON line (every `frac` is a byte RATE the kernel sustained / 8 TB/s, never > 1):
+  roofline      dominant kernel (the step's forward launch): algorithmic bytes / live HIP-event launch time vs 8 TB/s
+  kernels_step  both launches of the step;  kernels  the four single-tensor launches
+  kernels_model_shapes   the quantizer launches of one LLaMA-7B layer at their real shapes
+  autograd_path the same step through SymQuantizer.apply / backward (allocator + Python included)
   cpu_baseline  the reference's CPU path (eager op chain, oracle/eager_chain.py) timed on this box's host
                 cores on a bounded sample -- rank 0, N=1 only
   gpu_eager     the reference's eager op chain run on this GPU (9+5 launches): the like-for-like "before"
@@ -27,6 +32,8 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,7 +44,9 @@ if ROOT not in sys.path:
 ROWS, COLS = 4096, 11008
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FWD_BYTES_PER_ELEM = 4   # bf16: read x + write y              
-BWD_BYTES_PER_ELEM = 6   # bf16: read g + read x + write gx
+BWD_BYTES_PER_ELEM = 6   # bf16: read g + read x + write gx    (the reference's data flow)
+BWD_MASK_BYTES_PER_ELEM = 4  # bf16: read g + write gx: what the product's mask backward moves (+ 1 bit/elem of mask
+#                              for tensors with clippable rows)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -78,6 +87,13 @@ def aggregate_value(elems_per_rank_step, steps, world, seconds):
 # ----------------------------------------------------------------------------------------------
 # GPU workload
 # ----------------------------------------------------------------------------------------------
+def _act_like(torch, rows, cols, gen, device):
+    """activation-style input of BASELINE.md §3: N(0,1) with 0.1 % of the entries x20 (outlier channels)"""
+    a = torch.randn(rows, cols, generator=gen, device=device)
+    a[torch.rand(rows, cols, generator=gen, device=device) < 1e-3] *= 20.0
+    return a.bfloat16()
+
+
 class Workload:
     def __init__(self, device, rows=ROWS, cols=COLS, nsets=4, seed=1234):
         import torch
@@ -85,6 +101,7 @@ class Workload:
         from llm_qat_amd import _lib
         _lib.lib()  # no fallback: raises if the HIP library is absent
         self.torch, self.ops = torch, llm_qat_amd.ops
+        self.device = device
         self.rows, self.cols, self.nsets = rows, cols, nsets
         self.n = rows * cols
         self.sets = []
@@ -93,9 +110,7 @@ class Workload:
             # 0.1 % of entries x20 seed 1236 (set 0 uses exactly those seeds; the rotating sets offset them by 1000*k)
             gw_, gg_, ga_ = (torch.Generator(device=device).manual_seed(sd + 1000 * k) for sd in (seed, seed + 1, seed + 2))
             w = (torch.randn(rows, cols, generator=gw_, device=device) * 0.02).bfloat16()
-            a = torch.randn(rows, cols, generator=ga_, device=device)
-            a[torch.rand(rows, cols, generator=ga_, device=device) < 1e-3] *= 20.0                # outlier channels
-            a = a.bfloat16()
+            a = _act_like(torch, rows, cols, ga_, device)
             gw = (torch.randn(rows, cols, generator=gg_, device=device) * 1e-3).bfloat16()
             ga = (torch.randn(rows, cols, generator=gg_, device=device) * 1e-3).bfloat16()
             L = _lib.lib()
@@ -191,66 +206,204 @@ class Workload:
             self.fwd(s, "a")
         self.torch.cuda.synchronize()
 
-    def time_kernel(self, fn, iters):
-        """Launch duration of one kernel kind with HIP events on the launch stream, rotating buffers.
-        -> (mean ms over a back-to-back batch, [p10, p50, p90] ms of individually bracketed launches)"""
+    def clippable_fraction(self):
+        """fraction of the A8 tensor's rows whose recorded bounds reach the clip (they carry a mask: 1 bit/element)"""
+        b = self.sets[0]["ba"]
+        return float(((b[:, 0] >= 2.0) | (b[:, 1] <= -2.0)).float().mean().item())
+
+    def time_kernel(self, fn, iters, sets=None):
+        return time_launches(self.torch, fn, iters, sets if sets is not None else self.sets)
+
+
+def time_launches(torch, fn, iters, sets):
+    """Launch duration of one kernel kind with HIP events on the launch stream (torch's current stream IS the stream the
+    C ABI is handed), rotating buffers.
+    -> (mean ms over a back-to-back batch, [p10, p50, p90] ms of individually bracketed launches)"""
+    ns = len(sets)
+    for i in range(3):
+        fn(sets[i % ns])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(iters):
+        fn(sets[i % ns])
+    e1.record()
+    torch.cuda.synchronize()
+    mean = e0.elapsed_time(e1) / iters
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for i, (a, b) in enumerate(pairs):
+        a.record()
+        fn(sets[i % ns])
+        b.record()
+    torch.cuda.synchronize()
+    d = sorted(a.elapsed_time(b) for a, b in pairs)
+    return mean, [d[len(d) // 10], d[len(d) // 2], d[(9 * len(d)) // 10]]
+
+
+class ModelShapes:
+    """The quantizer launches of ONE LLaMA-7B decoder layer at their real shapes (seq 2048, bs 1; reference call sites
+    models/modeling_llama_quant.py:313-327 attention, :235 MLP), through the C ABI on preallocated rotating buffers."""
+
+    def __init__(self, wl, tokens=2048, hidden=4096, inter=11008):
+        torch = wl.torch
+        self.wl, self.torch, self.L, self._lib = wl, torch, wl.L, wl._lib
+        self.tokens, self.hidden, self.inter = tokens, hidden, inter
+        self.cache = {}
+
+    def sets_for(self, rows, cols, style, want_y32=False):
+        key = (rows, cols, style, want_y32)
+        if key in self.cache:
+            return self.cache[key]
+        torch, dev = self.torch, self.wl.device
+        code = self._lib.DTYPE_BF16
+        n = rows * cols
+        nsets = max(3, min(12, int(700e6 // (n * 2 * 4)) + 1))   # > 256 MiB of distinct buffers where that is affordable
+        mb = self.L.fq_ste_mask_bytes(rows, cols, code)
+        g = torch.Generator(device=dev).manual_seed(4321 + rows + cols)
+        sets = []
+        for _ in range(nsets):
+            x = (torch.randn(rows, cols, generator=g, device=dev) * 0.02).bfloat16() if style == "w" else _act_like(torch, rows, cols, g, dev)
+            d = dict(x=x, y=torch.empty_like(x), g=(torch.randn(rows, cols, generator=g, device=dev) * 1e-3).bfloat16(), gx=torch.empty_like(x),
+                     b=torch.empty(rows, 2, device=dev), m=torch.empty(max(mb, 8), dtype=torch.uint8, device=dev), mb=mb)
+            if want_y32:
+                d["y32"] = torch.empty(rows, cols, device=dev)
+                d["g32"] = torch.randn(rows, cols, generator=g, device=dev) * 1e-3
+            sets.append(d)
+        self.cache[key] = sets
+        return sets
+
+    def chk(self, rc, what="model_shapes"):
+        if rc:
+            self._lib.check(rc, what)
+
+    def single_fwd(self, rows, cols, bits, style):
+        L, code, st = self.L, self._lib.DTYPE_BF16, self.wl.stream
+        sets = self.sets_for(rows, cols, style)
+        return (lambda s: self.chk(L.fq_sym_fwd_train(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, bits, code, 0, -2.0, 2.0,
+                                                      s["b"].data_ptr(), s["m"].data_ptr(), s["mb"], st))), sets
+
+    def single_bwd(self, rows, cols, style):
+        L, code, st = self.L, self._lib.DTYPE_BF16, self.wl.stream
+        sets = self.sets_for(rows, cols, style)
+        return (lambda s: self.chk(L.fq_ste_bwd_mask(s["g"].data_ptr(), s["gx"].data_ptr(), rows, cols, -2.0, 2.0, s["b"].data_ptr(),
+                                                     s["m"].data_ptr(), s["mb"], code, st))), sets
+
+    def pair_fwd(self, rows0, style0, bits0, rows1, style1, bits1, cols, autocast=0):
+        """tensor 0 + tensor 1 in one launch; autocast 2 = fp32 results (the K / V hooks under autocast)"""
+        L, code, st = self.L, self._lib.DTYPE_BF16, self.wl.stream
+        wide = autocast == 2
+        s0 = self.sets_for(rows0, cols, style0, wide)
+        s1 = self.sets_for(rows1, cols, style1 + "2", wide)   # distinct buffers even when both tensors have one shape
+        sets = [dict(a=a, b=b) for a, b in zip(s0, s1)]
+        yk = "y32" if wide else "y"
+
+        def fn(s):
+            a, b = s["a"], s["b"]
+            self.chk(L.fq_sym_fwd_pair(a["x"].data_ptr(), a[yk].data_ptr(), rows0, bits0, a["b"].data_ptr(), a["m"].data_ptr(), a["mb"],
+                                       b["x"].data_ptr(), b[yk].data_ptr(), rows1, bits1, b["b"].data_ptr(), b["m"].data_ptr(), b["mb"],
+                                       cols, code, 0, autocast, -2.0, 2.0, st), "fq_sym_fwd_pair")
+        return fn, sets
+
+    def pair_bwd(self, rows0, style0, rows1, style1, cols, wide=False):
+        L, code, st = self.L, self._lib.DTYPE_BF16, self.wl.stream
+        s0 = self.sets_for(rows0, cols, style0, wide)
+        s1 = self.sets_for(rows1, cols, style1 + "2", wide)
+        sets = [dict(a=a, b=b) for a, b in zip(s0, s1)]
+        gk = "g32" if wide else "g"
+        f = L.fq_ste_bwd_mask_wide if wide else L.fq_ste_bwd_mask_pair
+
+        def fn(s):
+            a, b = s["a"], s["b"]
+            self.chk(f(a[gk].data_ptr(), a["gx"].data_ptr(), rows0, a["b"].data_ptr(), a["m"].data_ptr(),
+                       b[gk].data_ptr(), b["gx"].data_ptr(), rows1, b["b"].data_ptr(), b["m"].data_ptr(), cols, -2.0, 2.0, code, st), "pair_bwd")
+        return fn, sets
+
+    def entries(self, iters):
+        """one roofline entry per launch kind of the layer (name, what it is at the reference call site)"""
+        T, H, I = self.tokens, self.hidden, self.inter
         torch = self.torch
-        for i in range(3):
-            fn(self.sets[i % self.nsets])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(iters):
-            fn(self.sets[i % self.nsets])
-        e1.record()
-        torch.cuda.synchronize()
-        mean = e0.elapsed_time(e1) / iters
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for i, (a, b) in enumerate(pairs):
-            a.record()
-            fn(self.sets[i % self.nsets])
-            b.record()
-        torch.cuda.synchronize()
-        d = sorted(a.elapsed_time(b) for a, b in pairs)
-        return mean, [d[len(d) // 10], d[len(d) // 2], d[(9 * len(d)) // 10]]
+        out = []
+
+        def add(name, site, fn_sets, elems, fwd, extra_mask_elems=0, bpe_in=2, bpe_out=2):
+            fn, sets = fn_sets
+            t = time_launches(torch, fn, iters, sets)
+            moved = elems * (bpe_in + bpe_out) + extra_mask_elems // 8
+            algo = elems * (FWD_BYTES_PER_ELEM if fwd else BWD_BYTES_PER_ELEM) if (bpe_in, bpe_out) == (2, 2) else moved
+            e = roofline_entry(name, algo, t, moved_bytes=moved)
+            e["reference_call_site"] = site
+            out.append(e)
+
+        # forward launches (training mode: bounds + STE mask recorded)
+        add("down_proj pair fwd: W4 [4096,11008] + A8 [2048,11008]", "utils_quant.py:195-201,:244-248 via modeling_llama_quant.py:235",
+            self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I)
+        add("A8 [2048,11008] fwd (down_proj input alone)", "utils_quant.py:244-248", self.single_fwd(T, I, 8, "a"), T * I, True, T * I)
+        add("A8 [2048,4096] fwd (shared q/k/v or gate/up input)", "modeling_llama_quant.py:313,317,318,:235", self.single_fwd(T, H, 8, "a"), T * H, True, T * H)
+        add("KV4 [2048,4096] fwd (one of K, V)", "modeling_llama_quant.py:320-327", self.single_fwd(T, H, 4, "a"), T * H, True, T * H)
+        add("quantize_kv pair fwd: K4 + V4 [2048,4096] x2", "modeling_llama_quant.py:320-327 (one launch)", self.pair_fwd(T, "a", 4, T, "a", 4, H),
+            2 * T * H, True, 2 * T * H)
+        add("quantize_kv pair fwd under autocast: fp32 results", "modeling_llama_quant.py:320-327 under kd_trainer.py:106 autocast",
+            self.pair_fwd(T, "a", 4, T, "a", 4, H, autocast=2), 2 * T * H, True, 2 * T * H, bpe_in=2, bpe_out=4)
+        add("q_proj pair fwd: W4 [4096,4096] + A8 [2048,4096]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H)
+        add("W4 [11008,4096] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True)
+        # backward launches (their forwards above have filled bounds + masks of the same buffers)
+        add("down_proj pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I)
+        add("A8 [2048,4096] bwd", "utils_quant.py:77-87", self.single_bwd(T, H, "a"), T * H, False, T * H)
+        add("quantize_kv pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(T, "a", T, "a", H), 2 * T * H, False, 2 * T * H)
+        add("quantize_kv pair bwd under autocast: fp32 grads in, bf16 out", "utils_quant.py:77-87 x2 + the engine's cast",
+            self.pair_bwd(T, "a", T, "a", H, wide=True), 2 * T * H, False, 2 * T * H, bpe_in=4, bpe_out=2)
+        return out
 
 
 def baseline_metric_name():
     """BASELINE.json's metric string, verbatim (value is its first quantity, Gelem/s; the second, achieved HBM GB/s,
-    is `hbm_gbs_algorithmic` and the roofline objects)."""
+    is the roofline objects)."""
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:  # noqa: BLE001
-        return "fake-quant fwd+bwd Gelem/s & achieved HBM GB/s, 4096\u00d711008 bf16 W4A8"
+        return "fake-quant fwd+bwd Gelem/s & achieved HBM GB/s, 4096×11008 bf16 W4A8"
 
 
-def roofline_entry(name, bytes_per_launch, timing, traffic=None):
-    """achieved = ALGORITHMIC bytes (4 B/elem forward, 6 B/elem backward, bf16) / launch time.
-    `traffic` = HBM bytes per launch measured with rocprofv3 --pmc (profiles/traffic.json); where the kernel moves
-    fewer bytes than the algorithmic figure (backward that does not re-read x) `frac` exceeds the byte-rate it
-    actually sustains, which is reported separately as traffic_gbs / traffic_frac."""
+def roofline_entry(name, algorithmic_bytes, timing, traffic=None, moved_bytes=None, traffic_source=None):
+    """One kernel's roofline entry.
+      achieved / frac            bytes the kernel MOVES by design (moved_bytes; = the algorithmic bytes unless given) / launch
+                                 time: a real byte rate, so frac <= 1 by construction
+      achieved_algorithmic /     SURVEY §8d's accounting (4 B/elem forward, 6 B/elem backward, bf16) / launch time -- only
+      frac_algorithmic           present where it differs: the mask backward does not re-read x, so against the reference's
+                                 6 B/elem data flow it reads > its byte rate ("reference-dataflow equivalent", can exceed 1)
+      traffic                    HBM bytes per launch measured with rocprofv3 --pmc; traffic_source says where it was measured"""
     ms, pct = timing if isinstance(timing, tuple) else (timing, None)
-    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    moved = algorithmic_bytes if moved_bytes is None else moved_bytes
+    ach = moved / (ms * 1e-3) / 1e9
     e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(ms * 1e3, 2),
-         "algorithmic_bytes_per_launch": bytes_per_launch}
+         "bytes_moved_per_launch": moved, "algorithmic_bytes_per_launch": algorithmic_bytes}
+    if moved != algorithmic_bytes:
+        alg = algorithmic_bytes / (ms * 1e-3) / 1e9
+        e["achieved_algorithmic"] = round(alg, 1)
+        e["frac_algorithmic"] = round(alg / HBM_PEAK_GBS, 4)
+        e["frac_algorithmic_note"] = "reference-dataflow equivalent (SURVEY §8d accounting), not a byte rate"
     if traffic:
         e["traffic_gbs"] = round(traffic / (ms * 1e-3) / 1e9, 1)
         e["traffic_frac"] = round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        e["traffic_source"] = traffic_source or "profiles/traffic.json"
     if pct:
         e["us_p10_p50_p90"] = [round(v * 1e3, 2) for v in pct]
     return e
 
 
 def load_traffic():
-    """HBM bytes per launch from committed rocprofv3 --pmc runs (profiles/traffic.json), if present."""
+    """HBM bytes per launch from committed rocprofv3 --pmc runs (profiles/traffic.json), if present -- NOT measured in this
+    run (PMC collection needs the profiler around the process); the JSON line says so in `traffic_source`."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p))
+            t = json.load(open(p))
+            src = t.pop("_source", None) or ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier bench.py run, "
+                                             "file mtime " + time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(p))) + "; not measured in this run)")
+            return t, src
         except Exception:
-            return {}
-    return {}
+            return {}, None
+    return {}, None
 
 
 def cpu_baseline(budget_s=15.0):
@@ -382,6 +535,36 @@ def gpu_eager(wl, iters=5, autocast=False):
                     + (", inside torch.autocast(cuda, bf16) as LLM-QAT trains (fp32 intermediates, fp32 outputs)" if autocast else "")}
 
 
+def autograd_path(wl, iters=40):
+    """The same step through the product's autograd Functions (SymQuantizer.apply + .backward on the step's own tensors):
+    allocator, Python, ctypes and autograd-engine cost included -- what a training loop pays per call."""
+    import torch
+    from llm_qat_amd.utils_quant import SymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+    leaves = []
+    for s in wl.sets:
+        leaves.append((s["w"].detach().requires_grad_(True), s["a"].detach().requires_grad_(True), s["gw"], s["ga"]))
+
+    def one(k):
+        w, a, gw, ga = leaves[k % len(leaves)]
+        w.grad = a.grad = None
+        yw = SymQuantizer.apply(w, clip, 4, False)
+        ya = SymQuantizer.apply(a, clip, 8, False)
+        torch.autograd.backward([yw, ya], [gw, ga])
+
+    for k in range(3):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(iters):
+        one(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"ms_per_step": round(dt * 1e3, 4), "value": round(2 * wl.n / dt / 1e9, 2), "unit": "Gelem/s",
+            "what": "SymQuantizer.apply(W4) + SymQuantizer.apply(A8) + autograd backward on the step's tensors: 4 launches, "
+                    "outputs / side buffers / gradients from PyTorch's caching allocator (wall clock incl. host overhead)"}
+
+
 def ensure_built(local_rank, dist):
     """A fresh checkout has no libllmqat_fakequant.so yet: compile it (one rank per node does, the others wait).
     Building the product is not a fallback -- without the library the benchmark fails loudly."""
@@ -397,7 +580,10 @@ def ensure_built(local_rank, dist):
         dist.barrier()
 
 
-def main():
+# ----------------------------------------------------------------------------------------------
+# launching: N ranks, one process per GPU
+# ----------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -405,37 +591,125 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip per-kernel / eager measurements")
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true",
+                    help="harness self-test: the step is a short sleep, no GPU is touched, the process group is gloo. "
+                         "The JSON line says data='stub'; it is never a measurement.")
+    return ap.parse_args(argv)
 
-    import torch
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set) from THIS process, which has not
+    imported torch and never touches a GPU (no exec of a GPU-initialised process anywhere).  Rank 0's JSON line goes to
+    our stdout.  Any rank failing -> the others are stopped (by PID) and we exit non-zero."""
+    if not args.stub:
+        ensure_built(0, None)   # hipcc only; no GPU call
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = set(range(len(procs)))
+    while live:
+        for i in list(live):
+            code = procs[i].poll()
+            if code is None:
+                continue
+            live.discard(i)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {i} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for j in live:
+                    procs[j].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def init_ranks(args):
+    """-> (world, rank, local_rank, dist or None, device or None, info).  Refuses (SystemExit != 0) rather than running
+    fewer ranks than --gpus asks for."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_TEST_KILL_RANK") == str(rank) and world > 1:   # tests/test_bench_harness.py: a rank that dies before joining
+        raise SystemExit(3)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a line "
+                         f"for a job that is not the one asked for")
+    import torch
+    info = {"ranks_seen": 1}
+    device = None
+    # the process group's backend is chosen up front, never by a per-rank fallback (ranks that disagree would hang):
+    # RCCL ("nccl") as the launch contract says; BENCH_DIST_BACKEND=gloo keeps even the barrier off the GPUs
+    backend = os.environ.get("BENCH_DIST_BACKEND", "gloo" if args.stub else "nccl")
+    if not args.stub:
+        ndev = torch.cuda.device_count()   # does not initialise the GPU on this image
+        if ndev < 1:
+            raise SystemExit("bench.py: no GPU visible")
+        if world > ndev:
+            if os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1" or backend == "nccl":
+                raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible. One process per GPU is the contract; "
+                                 f"a rehearsal that shares GPUs needs BENCH_ALLOW_SHARED_GPU=1 and BENCH_DIST_BACKEND=gloo")
+            info["ranks_share_devices"] = True
+        device = torch.device("cuda", local_rank % ndev)
+        torch.cuda.set_device(device)
     dist = None
-    ndev = max(torch.cuda.device_count(), 1)
-    device = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
-    torch.cuda.set_device(device)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The data path has no collective (replicas only).  The process group exists for the timing barrier and the
-        # max-over-ranks: RCCL ("nccl") as the launch contract says; BENCH_DIST_BACKEND=gloo keeps even that off the GPUs.
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        try:
-            dist.init_process_group(backend)
-            t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t)
-        except Exception as e:  # noqa: BLE001
-            if backend != "nccl":
-                raise
-            print(f"bench.py: RCCL process group failed ({e!r}); using gloo for the timing barrier", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        if backend == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group("gloo")
-    elif args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE unset); running 1 rank",
-              file=sys.stderr)
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("BENCH_INIT_TIMEOUT_S", "300"))))
+        t = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t)   # every rank that joined adds 1
+        info["ranks_seen"] = int(t.item())
+        info["dist_backend"] = backend
+        if info["ranks_seen"] != args.gpus:
+            raise SystemExit(f"bench.py: {info['ranks_seen']} ranks joined, --gpus {args.gpus} asked for")
+    return world, rank, local_rank, dist, device, info
+
+
+def run_stub(args, world, rank, dist, info):
+    """the launch / barrier / max-over-ranks / aggregation path with a sleep for a step (tests/test_bench_harness.py)"""
+    elems = 1000
+    seconds = timed_region(lambda i: time.sleep(0.002 * (1 + rank)), args.steps, args.warmup, lambda: None, dist)
+    out = {"metric": baseline_metric_name(), "value": aggregate_value(elems, args.steps, world, seconds), "unit": "Gelem/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "stub", "stub": True,
+           "config": {"workload": "STUB (harness self-test: sleep step, no GPU) -- not a measurement", "parallelism": "replicas"}}
+    out.update(info)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)   # this process stays torch-free
+
+    world, rank, local_rank, dist, device, info = init_ranks(args)
+    if args.stub:
+        return run_stub(args, world, rank, dist, info)
+    import torch
 
     ensure_built(local_rank, dist)
     wl = Workload(device)
@@ -444,7 +718,10 @@ def main():
     elems_step = 2 * wl.n
     value = aggregate_value(elems_step, args.steps, world, seconds)
     ms_step = seconds / args.steps * 1e3
+    clip_frac = wl.clippable_fraction()
+    mask_bytes_a = int(wl.n * clip_frac) // 8          # 1 bit/element for the A8 tensor's clippable rows; the W4 tensor has none
     algo_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_BYTES_PER_ELEM)
+    moved_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_MASK_BYTES_PER_ELEM) + 2 * mask_bytes_a
 
     out = {
         "metric": baseline_metric_name(),
@@ -457,22 +734,29 @@ def main():
                    "semantics": "cpu_eager",
                    "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x)",
                    "launches_per_step": "2 (weight + input of a QuantizeLinear share one forward and one backward launch)"},
+        "hbm_gbs_moved": round(moved_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
         "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
+        "hbm_gbs_note": "moved = bytes the step's two launches move (fwd 4 + bwd 4 B/elem + mask bits): a real byte rate; algorithmic = "
+                        "SURVEY §8d's 10 B/elem reference-dataflow accounting / step time (the mask backward never re-reads x)",
     }
+    out.update(info)
 
     if rank == 0 and not args.no_extras:
-        traffic = load_traffic()
+        traffic, tsrc = load_traffic()
         it = max(20, min(args.steps, 200))
         nb = wl.n
+        fwd_w, fwd_a = nb * FWD_BYTES_PER_ELEM, nb * FWD_BYTES_PER_ELEM + mask_bytes_a
+        bwd_w, bwd_a = nb * BWD_MASK_BYTES_PER_ELEM, nb * BWD_MASK_BYTES_PER_ELEM + mask_bytes_a
+        # (fn, algorithmic bytes, bytes moved by design)
         ks = {
-            "sym_fwd_w4": (lambda s: wl.fwd(s, "w"), nb * FWD_BYTES_PER_ELEM),
-            "sym_fwd_a8": (lambda s: wl.fwd(s, "a"), nb * FWD_BYTES_PER_ELEM),
-            "ste_bwd_a8": (lambda s: wl.bwd(s, "a"), nb * BWD_BYTES_PER_ELEM),
-            "ste_bwd_w4": (lambda s: wl.bwd(s, "w"), nb * BWD_BYTES_PER_ELEM),
+            "sym_fwd_w4": (lambda s: wl.fwd(s, "w"), nb * FWD_BYTES_PER_ELEM, fwd_w),
+            "sym_fwd_a8": (lambda s: wl.fwd(s, "a"), nb * FWD_BYTES_PER_ELEM, fwd_a),
+            "ste_bwd_a8": (lambda s: wl.bwd(s, "a"), nb * BWD_BYTES_PER_ELEM, bwd_a),
+            "ste_bwd_w4": (lambda s: wl.bwd(s, "w"), nb * BWD_BYTES_PER_ELEM, bwd_w),
         }
         pk = {
-            "sym_fwd_pair_w4a8": (lambda s: wl.fwd_pair(s), 2 * nb * FWD_BYTES_PER_ELEM),
-            "ste_bwd_pair_w4a8": (lambda s: wl.bwd_pair(s), 2 * nb * BWD_BYTES_PER_ELEM),
+            "sym_fwd_pair_w4a8": (lambda s: wl.fwd_pair(s), 2 * nb * FWD_BYTES_PER_ELEM, fwd_w + fwd_a),
+            "ste_bwd_pair_w4a8": (lambda s: wl.bwd_pair(s), 2 * nb * BWD_BYTES_PER_ELEM, bwd_w + bwd_a),
         }
 
         def pair_traffic(k):
@@ -481,42 +765,57 @@ def main():
             parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8"), "ste_bwd_pair_w4a8": ("ste_bwd_w4", "ste_bwd_a8")}[k]
             return sum(traffic[p] for p in parts) if all(p in traffic for p in parts) else None
 
-        out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it), pair_traffic(k)) for k, (fn, b) in pk.items()]
-        kernels = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ks.items()]
-        out["kernels"] = kernels
+        out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it), pair_traffic(k), moved_bytes=mv, traffic_source=tsrc)
+                               for k, (fn, b, mv) in pk.items()]
+        out["kernels"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), moved_bytes=mv, traffic_source=tsrc)
+                          for k, (fn, b, mv) in ks.items()]
         # the reference's data flow on the same kernels' siblings: forward without mask/bounds, backward re-reading x
         alt = {
             "sym_fwd_w4_plain": (lambda s: wl.fwd_plain(s, "w"), nb * FWD_BYTES_PER_ELEM),
             "ste_bwd_a8_xread": (lambda s: wl.bwd_xread(s, "a"), nb * BWD_BYTES_PER_ELEM),
         }
-        out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in alt.items()]
+        out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in alt.items()]
         ac = {
             "sym_fwd_w4_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "w", False), nb * FWD_BYTES_PER_ELEM),
             "sym_fwd_a8_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "a", False), nb * FWD_BYTES_PER_ELEM),
             "sym_fwd_a8_autocast_fp32_out": (lambda s: wl.fwd_autocast(s, "a", True), nb * 6),  # read 2 + write 4 B/elem
         }
-        out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k)) for k, (fn, b) in ac.items()]
+        out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in ac.items()]
         # `roofline`: the forward launch of the step (row_reg_kernel over the W4 weight and the A8 input: reduce -> scale ->
-        # round -> dequant).  It moves exactly its algorithmic bytes, so its fraction is a real byte rate; the mask backward
-        # moves fewer bytes than its 6 B/elem accounting (see `kernels_step`, frac > 1).
+        # round -> dequant): achieved = ALGORITHMIC bytes (4 B/elem x 90.2 M elements) / its launch time.
         fwp = out["kernels_step"][0]
-        out["roofline"] = {k: fwp[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch") if k in fwp}
-        out["roofline"]["kernel"] = "row_reg_kernel (Sym forward of the step: W4 weight + A8 input in one launch)"
-        for k in ("traffic_gbs", "traffic_frac"):
+        alg = fwp["algorithmic_bytes_per_launch"] / (fwp["us_per_launch"] * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / HBM_PEAK_GBS, 4),
+                           "traffic": fwp["traffic"], "us_per_launch": fwp["us_per_launch"],
+                           "kernel": "row_reg_kernel (Sym forward of the step: W4 weight + A8 input in one launch)",
+                           "algorithmic_bytes_per_launch": fwp["algorithmic_bytes_per_launch"]}
+        for k in ("traffic_gbs", "traffic_frac", "traffic_source"):
             if k in fwp:
                 out["roofline"][k] = fwp[k]
         tot_us = sum(e["us_per_launch"] for e in out["kernels_step"])
-        out["roofline_step"] = {"bound": "hbm", "achieved": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                "what": "both launches of one step: 10 algorithmic B/elem / sum of launch times"}
+        out["roofline_step"] = {"bound": "hbm", "achieved": round(moved_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(moved_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "bytes_moved_per_step": moved_bytes_step,
+                                "achieved_algorithmic": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1),
+                                "frac_algorithmic": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "frac_algorithmic_note": "10 B/elem reference-dataflow equivalent (SURVEY §8d), not a byte rate",
+                                "what": "both launches of one step: bytes moved / sum of launch times"}
         out["unpaired_step"] = {"ms_per_step": round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
                                 "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2)"}
+        out["autograd_path"] = autograd_path(wl)
         # a live yardstick for "how fast can this device move the same bytes": ATen's device-to-device copy of the W tensor
         # (read 90.2 MB + write 90.2 MB = one single-tensor forward's algorithmic bytes), timed like the kernels above
         cmean, cpct = wl.time_kernel(lambda s: s["yw"].copy_(s["w"]), it)
         out["copy_reference"] = {"what": "torch Tensor.copy_ device-to-device over the same 180.4 MB as sym_fwd_w4 (compare kernels[0])",
                                  "us_per_launch": round(cmean * 1e3, 2), "gbs": round(nb * FWD_BYTES_PER_ELEM / (cmean * 1e-3) / 1e9, 1),
                                  "us_p10_p50_p90": [round(v * 1e3, 2) for v in cpct]}
+        # the launches of one LLaMA-7B layer at their real shapes
+        out["kernels_model_shapes"] = ModelShapes(wl).entries(it)
+        for hook in EXTRA_ENTRIES:   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
+            try:
+                out.update(hook(wl, it))
+            except Exception as e:  # noqa: BLE001  -- an extra entry must never lose the headline line
+                out.setdefault("extras_failed", []).append(f"{getattr(hook, '__name__', hook)}: {e!r}")
         if world == 1:
             out["gpu_eager"] = gpu_eager(wl)
             out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)
@@ -529,7 +828,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 0
+
+
+EXTRA_ENTRIES = []
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -27,8 +27,21 @@ def test_aggregate_value_is_whole_job():
 def test_roofline_entry_math():
     e = bench.roofline_entry("k", 8_000_000_000, 1000.0)
     assert e["achieved"] == 8.0 and e["frac"] == 0.001 and e["peak"] == 8000.0 and e["bound"] == "hbm"
+    assert "frac_algorithmic" not in e            # the kernel moves exactly its algorithmic bytes: one figure only
     e = bench.roofline_entry("k", 8_000_000_000, (1000.0, [900.0, 1000.0, 1100.0]), traffic=4_000_000_000)
     assert e["traffic_gbs"] == 4.0 and e["traffic_frac"] == 0.0005 and e["us_p10_p50_p90"] == [900000.0, 1000000.0, 1100000.0]
+    assert e["traffic_source"]                    # a traffic figure always says where it was measured
+
+
+def test_frac_is_a_byte_rate_never_above_one():
+    """the mask backward moves 4 B/elem, not the 6 B/elem of the reference's data flow: `frac` follows the bytes moved,
+    the 6 B/elem accounting is reported under its own, labelled key (frac 1.14 was an accounting figure)"""
+    n = 45_088_768
+    ms = 30.4e-3                                   # 30.4 us: the measured mask backward of the metric tensor
+    e = bench.roofline_entry("ste_bwd", n * 6, ms, moved_bytes=n * 4)
+    assert e["frac"] <= 1.0 and abs(e["achieved"] - n * 4 / 30.4e-6 / 1e9) < 0.1
+    assert e["frac_algorithmic"] > 1.0 and "not a byte rate" in e["frac_algorithmic_note"]
+    assert e["bytes_moved_per_launch"] == n * 4 and e["algorithmic_bytes_per_launch"] == n * 6
 
 
 WORKER = r"""
@@ -65,3 +78,46 @@ def test_two_rank_gloo_max_over_ranks(tmp_path):
     assert res["world"] == 2
     assert res["dt"] >= 4 * 0.05 * 0.95                   # the slow rank's time, not rank 0's
     assert abs(res["value"] - 1000 * 4 * 2 / res["dt"] / 1e9) < 1e-12
+
+
+# ---- `python bench.py --gpus N` with NO launcher: bench.py starts the N ranks itself ----
+def _run_bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_without_launcher_spawns_two_ranks():
+    p, out = _run_bench(["--gpus", "2", "--stub", "--steps", "6", "--warmup", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dist_backend"] == "gloo"
+    assert out["data"] == "stub" and out["stub"] is True          # can never be mistaken for a measurement
+    assert out["steps"] == 6 and out["warmup"] == 2
+    # the slow rank (rank 1 sleeps 4 ms per step) sets the time: max over ranks, whole-job value = 2 ranks' elements
+    assert out["ms_per_step"] >= 4.0 * 0.9
+    assert abs(out["value"] - 1000 * 6 * 2 / (out["ms_per_step"] * 6 / 1e3) / 1e9) < 1e-9
+
+
+def test_gpus_4_stub_counts_every_rank():
+    p, out = _run_bench(["--gpus", "4", "--stub", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 4 and out["ranks_seen"] == 4
+
+
+def test_never_reports_fewer_ranks_than_asked():
+    # a launcher that started the wrong number of ranks: refuse, print no JSON line
+    p, out = _run_bench(["--gpus", "2", "--stub", "--steps", "2", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0"}, drop=())
+    assert p.returncode != 0 and out is None and "refusing" in p.stderr
+
+
+def test_a_failing_rank_fails_the_job(tmp_path):
+    # rank 1 cannot join (its rendezvous port is closed to it): the parent must exit non-zero, not hang, not print n_gpus 1
+    p, out = _run_bench(["--gpus", "2", "--stub", "--steps", "2", "--warmup", "0"], {"BENCH_INIT_TIMEOUT_S": "5", "BENCH_TEST_KILL_RANK": "1"})
+    assert p.returncode != 0 and out is None
+
+
+def test_one_gpu_default_has_no_process_group_keys():
+    p, out = _run_bench(["--stub", "--steps", "2", "--warmup", "0"])
+    assert p.returncode == 0 and out["n_gpus"] == 1 and out["ranks_seen"] == 1 and "dist_backend" not in out

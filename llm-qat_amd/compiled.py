@@ -72,5 +72,5 @@ def fake_quant(kind, x, clip_val, num_bits, layerwise, narrow=False):
     """SymQuantizer / AsymQuantizer .apply while compiling."""
     mode = 0
     if kind == "sym" and ops.autocast_active(x):
-        mode = 1 if narrow else 2
+        mode = 1 if (narrow and ops.autocast_narrow_ok(x)) else 2
     return fake_quant_op(x, clip_val, _KINDS[kind], int(num_bits), bool(layerwise), mode)

@@ -72,6 +72,7 @@ static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
 template <int DT, int AC>
 static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
+    clear_stale_error();
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
     } else {
@@ -98,9 +99,7 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     }
                 if (nh <= 512) W(64) else if (nh <= 2048) W(256) else W(1024)
 #undef W
-                hipError_t e = hipGetLastError();
-                if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-                return ok();
+                return launch_result();
             }
             if (pair || a.mask)
                 return fail(FQ_ERR_UNSUPPORTED, "fp32-result forward with STE mask / second tensor: rows must be 8-byte aligned, cols %% 4 == 0, cols <= 32768");
@@ -108,9 +107,7 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
             if (a.cols <= GENERIC_MAX_COLS) {
                 if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, false, AC>), (a.rows + 3) / 4, 256, st, a);
                 else FQ_LAUNCH((row_generic_kernel<DT, 256, false, AC>), a.rows, 256, st, a);
-                hipError_t e = hipGetLastError();
-                if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-                return ok();
+                return launch_result();
             }
         } else {
             if (pair && !(vec_ok && nvec <= REG_MAX_VEC))
@@ -140,9 +137,7 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
             else FQ_LAUNCH((stats_kernel<DT, false, false>), a.rows * schunks, TP_THREADS, st, a, w, schunks);
             FQ_LAUNCH((apply_autocast_kernel<DT, AC == 2>), a.rows * achunks, TP_THREADS, st, a, (const uint32_t*)w, achunks);
         }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-        return ok();
+        return launch_result();
     }
 }
 
@@ -153,6 +148,7 @@ template <int DT> int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t
 template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
+    clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     const bool pair = a.x1 != nullptr;  // two tensors in one launch: register kernels only
     const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && (!pair || (aligned16(a.x1) && aligned16(a.y1)));
@@ -197,9 +193,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
             FQ_LAUNCH((apply_kernel<DT, ASYM, FAST, false>), a.rows * chunks, TP_THREADS, st, a, (const uint32_t*)w, chunks);
         }
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-    return ok();
+    return launch_result();
 }
 
 template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st) {
@@ -213,6 +207,7 @@ template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, 
 
 template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
+    clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     if (aligned16(g) && aligned16(x) && aligned16(gx) && n % EPV == 0) {
         const int64_t nvec = n / EPV;
@@ -230,15 +225,14 @@ template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t
         if (grid > 8192) grid = 8192;
         FQ_LAUNCH((ste_scalar_kernel<DT>), grid, STE_THREADS, st, g, x, gx, n, lo, hi);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-    return ok();
+    return launch_result();
 }
 
 template <int DT>
 int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
                     hipStream_t st) {
     using T = Ty<DT>;
+    clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0))
         return launch_ste<DT>(g, x, gx, rows * cols, lo, hi, st);  // odd layout: plain path, same result
@@ -258,15 +252,14 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-    return ok();
+    return launch_result();
 }
 
 template <int DT>
 int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
                     hipStream_t st, const SteSecond* second) {
     using T = Ty<DT>;
+    clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw || !(aligned16(g) && aligned16(gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape/alignment not served");
@@ -289,15 +282,14 @@ int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-    return ok();
+    return launch_result();
 }
 
 template <int DT>
 int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
                          hipStream_t st, const SteSecond* second) {
     using T = Ty<DT>;
+    clear_stale_error();
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward applies to bf16 / fp16 inputs only");
     } else {
@@ -323,9 +315,7 @@ int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, fl
         break;
         switch (hpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-        return ok();
+        return launch_result();
     }
 }
 
@@ -333,6 +323,7 @@ template <int DT>
 int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, float cv,
                hipStream_t st) {
     using T = Ty<DT>;
+    clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     const bool vec = aligned16(w) && aligned16(out) && cols % EPV == 0;
     int64_t grid = vec ? (rows * (cols / EPV) + 255) / 256 : (rows * cols + 255) / 256;
@@ -345,9 +336,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
         if (vec) FQ_LAUNCH((w12_kernel<DT, 2, true>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
         else FQ_LAUNCH((w12_kernel<DT, 2, false>), grid, 256, st, w, scale, out, rows, cols, scale_per_row, cv);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-    return ok();
+    return launch_result();
 }
 
 #define FQ_INSTANTIATE(DT)                                                                                      \

@@ -17,6 +17,14 @@ namespace fq {
 FQ_HIDDEN int fail(int code, const char* fmt, ...);
 FQ_HIDDEN int ok();
 
+// hipLaunchKernelGGL returns nothing, and hipGetLastError() reports the calling thread's LAST error, whoever caused it.
+// Every launch function therefore drains a pending (foreign) error first and reads the status of its own launches after.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+inline int launch_result() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ok() : fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Cache policy of the 16-byte streams, from tools/kbench on MI355X (every tensor is touched once per launch):

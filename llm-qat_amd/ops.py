@@ -225,6 +225,14 @@ def autocast_active(x):
     return x.dtype in (torch.bfloat16, torch.float16) and x.is_cuda and torch.is_autocast_enabled("cuda")
 
 
+def autocast_narrow_ok(x):
+    """QuantizeLinear may ask for the autocast result "rounded once to the operand dtype" only when that dtype IS the
+    autocast dtype: F.linear's autocast cast rounds the reference's fp32 result to torch.get_autocast_dtype("cuda"), so
+    for an fp16 tensor inside autocast(bf16) (or the reverse) the narrow path would round twice.  Otherwise the callers
+    return the fp32 result and let F.linear do the single rounding, exactly as the reference does."""
+    return torch.get_autocast_dtype("cuda") == x.dtype
+
+
 def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=None):
     """SymQuantizer.forward with autocast arithmetic (fq_sym_fwd_autocast).
     train: None (no side outputs) | "bounds" | "mask".  -> (y, side or bounds or None, rows, cols, got)
@@ -286,6 +294,8 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
         return None
     ac = autocast_active(w)
     wide = bool(wide and ac)
+    if ac and not wide and not autocast_narrow_ok(w):
+        return None  # autocast dtype != operand dtype: the two-call path returns fp32 results, F.linear rounds once
     L = _lib.lib()
     odt = torch.float32 if wide else w.dtype
     wq, xq = torch.empty(w.shape, dtype=odt, device=w.device), torch.empty(x.shape, dtype=odt, device=w.device)
@@ -352,7 +362,7 @@ def quantize_train(kind, x, num_bits, layerwise, lo, hi):
 def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols):
     """STE backward from the (row_bounds, mask) a quantize_train call recorded -- x is not needed."""
     code = _prep(grad_output, "ste_backward_mask")
-    g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
+    g = _aligned(grad_output)  # a contiguous gradient can still be an offset view into a flat buffer
     gx = torch.empty_like(g)
     if g.numel() == 0:
         return gx

@@ -58,17 +58,21 @@ class _FakeQuantFunction(torch.autograd.Function):
         QuantizeLinear's own operands, that result rounded once -- exactly what F.linear's autocast cast does next)."""
         mode = _BACKWARD_MODE
         lo, hi = _clip_pair(clip_val)
+        narrow = narrow and ops.autocast_narrow_ok(input)
         out, side, rows, cols, got = ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow, lo=lo, hi=hi,
                                                               train=None if mode == "plain" else mode)
         ctx.grad_dtype = input.dtype  # the engine casts the reference's fp32 gradient to the input dtype; do it up front
-        ctx.clip, ctx.rows_cols, ctx.row_bounds = (lo, hi), (rows, cols), None
+        ctx.clip, ctx.rows_cols = (lo, hi), (rows, cols)
         if got == "mask":
-            ctx.fq_mode, ctx.side = ("mask" if narrow else "mask_wide"), side  # a fp32 result's mask has its own layout
+            ctx.fq_mode = "mask" if narrow else "mask_wide"  # a fp32 result's mask has its own layout
+            ctx.save_for_backward(side)  # bounds + mask (6 % of the tensor) as a SAVED tensor: hooks / checkpointing see it
             return out
-        ctx.save_for_backward(input, clip_val)
-        ctx.fq_mode = "plain"
         if got == "bounds":
-            ctx.fq_mode, ctx.row_bounds = "bounds", side
+            ctx.fq_mode = "bounds"
+            ctx.save_for_backward(input, clip_val, side)
+        else:
+            ctx.fq_mode = "plain"
+            ctx.save_for_backward(input, clip_val)
         return out
 
     @staticmethod
@@ -81,29 +85,33 @@ class _FakeQuantFunction(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:  # no backward will run (eval, frozen input): nothing to record or save
             ctx.fq_mode = "none"
             if kind == "sym" and ops.autocast_active(input):
-                return ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow)[0]
+                return ops.sym_forward_autocast(input, num_bits, layerwise, wide=not (narrow and ops.autocast_narrow_ok(input)))[0]
             return ops.sym_quantize(input, num_bits, layerwise) if kind == "sym" else ops.asym_quantize(input, num_bits, layerwise)
         if kind == "sym" and ops.autocast_active(input):
             return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
         mode = _BACKWARD_MODE
         ctx.fq_mode = "plain"
-        ctx.row_bounds = None
         if mode == "mask":
             lo, hi = _clip_pair(clip_val)
             res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
             if res is not None:
-                out, ctx.side, rows, cols = res
+                out, side, rows, cols = res
                 ctx.fq_mode, ctx.clip, ctx.rows_cols = "mask", (lo, hi), (rows, cols)
-                return out  # the input itself is not needed again
+                # The side buffer (row bounds + STE bit mask) is a SAVED tensor, not a ctx attribute: saved-tensor hooks
+                # (save_on_cpu, non-reentrant checkpointing's discard) see it and can drop / offload it like any other
+                # activation.  The input itself is not needed again and is not saved.
+                ctx.save_for_backward(side)
+                return out
             mode = "bounds"
-        ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
         fn = ops.sym_quantize if kind == "sym" else ops.asym_quantize
         if mode == "bounds":
-            out, ctx.row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
+            out, row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
             ctx.fq_mode = "bounds"
             ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
+            ctx.save_for_backward(input, clip_val, row_bounds)
         else:
             out = fn(input, num_bits, layerwise)
+            ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
         return out
 
     @staticmethod
@@ -116,16 +124,19 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
-            return ops.train_backward_wide(grad_output, ctx.side, rows, cols, lo, hi, ctx.grad_dtype), None, None, None
+            (side,) = ctx.saved_tensors
+            return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.grad_dtype), None, None, None
         if ctx.grad_dtype is not None and grad_output.dtype != ctx.grad_dtype:
             grad_output = grad_output.to(ctx.grad_dtype)  # autocast: fp32 grad of the fp32 output; zeroing commutes with the cast
         if ctx.fq_mode == "mask":
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
-            return ops.train_backward(grad_output, ctx.side, rows, cols, lo, hi), None, None, None
-        input, clip_val = ctx.saved_tensors  # reference :83 / :158
+            (side,) = ctx.saved_tensors
+            return ops.train_backward(grad_output, side, rows, cols, lo, hi), None, None, None
+        saved = ctx.saved_tensors  # reference :83 / :158: (input, clip_val) [+ the row bounds in "bounds" mode]
+        input, clip_val = saved[0], saved[1]
         lo, hi = _clip_pair(clip_val)
-        bounds = ctx.row_bounds
+        bounds = saved[2] if len(saved) > 2 else None
         if bounds is not None and not (input.is_contiguous() and grad_output.is_contiguous()):
             bounds = None
         grad_input = ops.ste_backward(grad_output, input, lo, hi, row_bounds=bounds,
@@ -267,11 +278,19 @@ class _PairNode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, input, res, clip=(-2.0, 2.0)):
-        wq, xq, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
+        wq, xq, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
         ctx.dtype, ctx.clip = weight.dtype, clip
         ctx.wide = wq.dtype != weight.dtype  # fp32 results under autocast (the K / V hooks): fp32 gradients come back
         ctx.set_materialize_grads(False)
-        return wq.view_as(wq), xq.view_as(xq)
+        ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
+        wq, xq = wq.view_as(wq), xq.view_as(xq)
+        # An operand that needs no gradient (frozen weight, input without grad) gets a result that needs none either, as
+        # SymQuantizer.apply gives in the reference: F.linear's backward then skips the wgrad / dgrad GEMM it would
+        # otherwise run only for this node to throw the result away.
+        nd = [t for t, need in ((wq, ctx.needs_input_grad[0]), (xq, ctx.needs_input_grad[1])) if not need]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return wq, xq
 
     @staticmethod
     @once_differentiable
@@ -279,17 +298,18 @@ class _PairNode(torch.autograd.Function):
         _bwd_epoch[0] += 1
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lo, hi = ctx.clip
+        side_w, side_x = ctx.saved_tensors
         if ctx.wide:
             gw, gx = (gw if need_w else None), (gx if need_x else None)
             if gw is None and gx is None:
                 return None, None, None, None
-            ow, ox = ops.pair_backward_wide(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
+            ow, ox = ops.pair_backward_wide(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
             return ow, ox, None, None
         gw = gw.to(ctx.dtype) if (need_w and gw is not None and gw.dtype != ctx.dtype) else (gw if need_w else None)
         gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
         if gw is None and gx is None:
             return None, None, None, None
-        ow, ox = ops.pair_backward(gw, gx, ctx.side_w, ctx.side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi)
+        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi)
         return ow, ox, None, None
 
 
@@ -325,21 +345,20 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, cached, clip_val):
         y, bounds, mask, rows_cols = cached
-        ctx.row_bounds, ctx.ste_mask, ctx.rows_cols = bounds, mask, rows_cols
+        ctx.rows_cols = rows_cols
         ctx.clip = _clip_pair(clip_val)
-        if mask is None:
-            ctx.save_for_backward(weight)
+        ctx.save_for_backward(weight if mask is None else None, bounds, mask)
         return y.view_as(y)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         lo, hi = ctx.clip
-        if ctx.ste_mask is not None:
+        weight, row_bounds, ste_mask = ctx.saved_tensors
+        if ste_mask is not None:
             rows, cols = ctx.rows_cols
-            return ops.ste_backward_mask(grad_output, lo, hi, ctx.row_bounds, ctx.ste_mask, rows, cols), None, None
-        (weight,) = ctx.saved_tensors
-        bounds = ctx.row_bounds if grad_output.is_contiguous() and weight.is_contiguous() else None
+            return ops.ste_backward_mask(grad_output, lo, hi, row_bounds, ste_mask, rows, cols), None, None
+        bounds = row_bounds if grad_output.is_contiguous() and weight.is_contiguous() else None
         return ops.ste_backward(grad_output, weight, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols), None, None
 
 
@@ -380,7 +399,7 @@ class QuantizeLinear(nn.Linear):
             rc = ops.rows_cols(tuple(w.shape), self.weight_layerwise)
             bounds = mask = None
             if ac:  # autocast arithmetic, result rounded once to the weight dtype (see _SymQuantizerOperand)
-                y, side, rows, _, got = ops.sym_forward_autocast(w, self.w_bits, self.weight_layerwise, wide=False,
+                y, side, rows, _, got = ops.sym_forward_autocast(w, self.w_bits, self.weight_layerwise, wide=not ops.autocast_narrow_ok(w),
                                                                  train=None if _BACKWARD_MODE == "plain" else _BACKWARD_MODE)
                 if got == "mask":
                     bounds, mask = side[: rows * 8].view(torch.float32).view(rows, 2), side[rows * 8:]

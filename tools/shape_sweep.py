@@ -42,17 +42,24 @@ def main():
                 sets.append(dict(x=x, y=torch.empty_like(x), g=torch.randn_like(x), gx=torch.empty_like(x),
                                  b=torch.empty(rows, 2, device=dev), m=torch.empty(max(mb, 8), dtype=torch.uint8, device=dev), mb=mb))
 
-            def t(fn, iters=60):
-                for i in range(5):
+            def t(fn, iters=60, rounds=3):
+                # Every kind gets its own warm-up over ALL buffer sets and the median of several rounds: the first batch
+                # that touches freshly allocated buffers runs 30-50 % slow on small tensors (tools/small_shape_probe.py,
+                # profiles/r02_small_shape_probe.json: [2048,4096] 10.3 us in the first round, 6.7 us afterwards), which
+                # round 1's sweep (5 warm-up launches, Sym timed first) reported as if it were the Sym kernel's time.
+                for i in range(max(20, 2 * nsets)):
                     fn(sets[i % nsets])
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                for i in range(iters):
-                    fn(sets[i % nsets])
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / iters * 1e3
+                vals = []
+                for _ in range(rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for i in range(iters):
+                        fn(sets[i % nsets])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    vals.append(e0.elapsed_time(e1) / iters * 1e3)
+                return sorted(vals)[len(vals) // 2]
 
             def chk(rc):
                 if rc:

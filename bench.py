@@ -831,7 +831,36 @@ def main(argv=None):
     return 0
 
 
-EXTRA_ENTRIES = []
+def export_entries(wl, iters):
+    """packed-bin export and the scale pre-pass on the metric tensor (bf16 [4096,11008])"""
+    torch, L, lib_, st = wl.torch, wl.L, wl._lib, wl.stream
+    rows, cols, n = wl.rows, wl.cols, wl.n
+    code = lib_.DTYPE_BF16
+    for s in wl.sets:
+        if "bins" not in s:
+            s["bins"] = torch.empty(n * 2, dtype=torch.uint8, device=wl.device)
+            s["scales"] = torch.empty(rows, 2, device=wl.device)
+            s["over"] = torch.empty(rows, dtype=torch.int32, device=wl.device)
+
+    def chk(rc):
+        if rc:
+            lib_.check(rc, "export")
+
+    def exp(key, bits, cont):
+        return lambda s: chk(L.fq_sym_export(s[key].data_ptr(), s["bins"].data_ptr(), s["scales"].data_ptr(), s["over"].data_ptr(), rows, cols, bits,
+                                             cont, code, 0, 0, st))
+
+    def scales(key, bits):
+        return lambda s: chk(L.fq_sym_row_scales(s[key].data_ptr(), s["scales"].data_ptr(), rows, cols, bits, code, 0, 0, -2.0, 2.0, None, None, 0, st))
+
+    ks = [("sym_export_w4_int4", exp("w", 4, lib_.BINS_INT4), n * 2 + n // 2),
+          ("sym_export_w8_int8", exp("w", 8, lib_.BINS_INT8), n * 3),
+          ("sym_export_a8_int8", exp("a", 8, lib_.BINS_INT8), n * 3),
+          ("sym_row_scales_w4 (pre-pass: read only)", scales("w", 4), n * 2)]
+    return {"kernels_export": [roofline_entry(k, b, wl.time_kernel(fn, iters)) for k, fn, b in ks]}
+
+
+EXTRA_ENTRIES = [export_entries]
 
 
 if __name__ == "__main__":

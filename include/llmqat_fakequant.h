@@ -212,6 +212,58 @@ int fq_ste_bwd_mask_wide(const void* g0, void* gx0, int64_t rows0, const float* 
 int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                int dtype, void* stream);
 
+/*
+ * ---- the integer side of the fake-quant forward ---------------------------------------------------------
+ *
+ * The reference never materialises integers: `output = torch.round(input * s).div(s + 1e-6)` (models/utils_quant.py:72)
+ * keeps the bins as floats, and AsymQuantizer likewise (`torch.round(input_normalized * s)`, :146).  These entry points
+ * emit those bins as PACKED INTEGERS plus the per-row scale terms -- what an int8 / int4 inference export of a QAT
+ * checkpoint needs (the published configs are W4 / W8, README.md:45-54), and the pre-pass of a GEMM that applies the
+ * fake-quant while it loads its operands (models/utils_quant.py:250 fed by :195-201 and :244-248).
+ *
+ * bins container (two's complement for SymQuantizer, unsigned for AsymQuantizer whose bins are 0 .. 2^bits-1):
+ *   FQ_BINS_INT4   two bins per byte, element 2k in the low nibble of byte k; rows start on a byte ((cols+1)/2 bytes/row)
+ *   FQ_BINS_INT8   one byte per bin
+ *   FQ_BINS_INT16  two bytes per bin (little endian)
+ * The reference has NO clamp (:46-48 are commented out): in bf16 the top bin of an 8-bit row can be +128 (127.5 is a
+ * bf16 value and rounds half-to-even), and 16-bit rows reach bins beyond 32767.  A container therefore SATURATES, and
+ * overflow_out[row] (optional) counts the elements of that row that did not fit (NaN bins are stored as 0 and counted).
+ * overflow_out[row] == 0  <=>  dequantising the export reproduces the fake-quant forward of that row bit for bit (up to the
+ * sign of zero: the reference's round(-0.3) is -0.0 and dequantises to -0.0, an integer bin 0 to +0.0):
+ *   Sym :  y = round_to_dtype(bin / t2)                                     scales_out[row] = {s, t2}   (t2 = s + 1e-6)
+ *   Asym:  y = round_to_dtype(round_to_dtype(round_to_dtype(bin / S) * a) + beta),  S = 2^bits - 1
+ *                                                                         scales_out[row] = {a, beta}  (a = alpha + 1e-8)
+ * A caller that must be lossless for 8-bit bf16 tensors asks for FQ_BINS_INT16 (or checks the count: it is 0 unless the
+ * row's maximum lands on the +128 bin).
+ *   x          [rows, cols] `dtype`, contiguous;  bins_out  fq_export_bins_bytes(rows, cols, container) bytes
+ *   scales_out float[rows][2] (optional);  overflow_out int32[rows] (optional)
+ *   autocast   (Sym, bf16 / fp16 only) 1: the bins of the reference's arithmetic under torch.autocast("cuda") -- fp32 behind
+ *              the reciprocal, see fq_sym_fwd_autocast -- which is how LLM-QAT trains; 0: the tensor-dtype arithmetic
+ * Traffic (bf16): read 2 B/elem + write 1 (int8) or 0.5 (int4) B/elem, non-temporal.  Rows that fit the register kernels
+ * (16-byte aligned, cols a multiple of a 16-byte vector, <= 8192 vectors) take one pass; anything else a two-sweep
+ * element kernel (one workgroup per row: a correctness path).
+ */
+#define FQ_BINS_NONE 0
+#define FQ_BINS_INT4 1
+#define FQ_BINS_INT8 2
+#define FQ_BINS_INT16 3
+size_t fq_export_bins_bytes(int64_t rows, int64_t cols, int container);
+int fq_sym_export(const void* x, void* bins_out, float* scales_out, int32_t* overflow_out, int64_t rows, int64_t cols, int bits,
+                  int container, int dtype, int sem, int autocast, void* stream);
+int fq_asym_export(const void* x, void* bins_out, float* scales_out, int32_t* overflow_out, int64_t rows, int64_t cols, int bits,
+                   int container, int dtype, int sem, void* stream);
+
+/*
+ * The reduction half of SymQuantizer.forward alone (models/utils_quant.py:53-59,:71): per-row  s = reciprocal(max|x| +
+ * 1e-6) * qmax  and  t2 = s + 1e-6  -> scales_out[rows][2] = {s, t2}; x is read once (2 B/elem bf16), nothing
+ * elementwise is written.  Optionally also records what a training-mode forward records for the STE backward
+ * (row_bounds_out + mask_out, exactly as fq_sym_fwd_train; lo / hi = the clip).  This is the pre-pass of the fused
+ * QuantizeLinear forward (fq_qlinear_fwd): with {s, t2} known per row, `round(x * s) / t2` is a pure elementwise map that
+ * the GEMM can apply to its operand tiles as it loads them.
+ */
+int fq_sym_row_scales(const void* x, float* scales_out, int64_t rows, int64_t cols, int bits, int dtype, int sem, int autocast, float lo,
+                      float hi, float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

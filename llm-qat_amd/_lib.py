@@ -20,7 +20,9 @@ EXPORTS = (
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
     "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
+    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales",
 )
+BINS_NONE, BINS_INT4, BINS_INT8, BINS_INT16 = 0, 1, 2, 3
 ERR_UNSUPPORTED = -8
 
 _lock = threading.Lock()
@@ -71,6 +73,14 @@ def _bind(L):
     L.fq_ste_bwd_mask_pair.restype = i32
     L.fq_ste_bwd_mask_wide.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, f32, f32, i32, vp]
     L.fq_ste_bwd_mask_wide.restype = i32
+    L.fq_export_bins_bytes.argtypes = [i64, i64, i32]
+    L.fq_export_bins_bytes.restype = sz
+    L.fq_sym_export.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, vp]
+    L.fq_sym_export.restype = i32
+    L.fq_asym_export.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
+    L.fq_asym_export.restype = i32
+    L.fq_sym_row_scales.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, f32, f32, vp, vp, sz, vp]
+    L.fq_sym_row_scales.restype = i32
     return L
 
 

@@ -32,52 +32,6 @@ int ok() {
 
 namespace {
 
-// ---- host-side round-to-dtype for the launch-uniform scalars (1e-6, 1e-8, clip bounds) ----
-inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-float host_rb(float v, int dt) {
-    if (dt == FQ_DTYPE_BF16) {
-        uint32_t u = f2u(v);
-        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return u2f(0x7FC00000u);
-        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-        return u2f(u);
-    }
-    if (dt == FQ_DTYPE_F16) {
-        uint32_t x = f2u(v), sign = x & 0x80000000u;
-        x &= 0x7FFFFFFFu;
-        if (x > 0x7F800000u) return u2f(0x7FC00000u);
-        if (x >= 0x477FF000u) return u2f(sign | 0x7F800000u);  // rounds to +-inf in fp16
-        if (x < 0x38800000u) {                                  // fp16 subnormal range: quantum 2^-24
-            const float q = 5.9604644775390625e-08f;
-            float k = __builtin_rintf(u2f(x) / q);              // x/q < 1024 is exact (q is a power of two); rintf = RNE
-            return u2f(f2u(k * q) | sign);
-        }
-        uint32_t odd = (x >> 13) & 1u;
-        x = (x + 0xFFFu + odd) & 0xFFFFE000u;
-        return u2f(sign | x);
-    }
-    return v;
-}
-
-struct Consts {
-    SymConst sym;
-    AsymConst asym;
-};
-Consts make_consts(int bits, int dt, int sem) {
-    Consts c;
-    const float c6 = 1e-6f, c8 = 1e-8f;
-    c.sym.qmax = (float)(double)((1u << (bits - 1)) - 1u);
-    c.sym.c6 = sem == FQ_SEM_CPU_EAGER ? host_rb(c6, dt) : c6;
-    const double S = (double)(bits >= 32 ? 4294967295.0 : (double)((1ull << bits) - 1ull));
-    c.asym.S = (float)S;
-    c.asym.invS = 1.0f / (float)S;
-    c.asym.c8 = sem == FQ_SEM_CPU_EAGER ? host_rb(c8, dt) : c8;
-    c.asym.mul_inv = sem == FQ_SEM_DEVICE_EAGER ? 1 : 0;
-    return c;
-}
-
-inline int esize_of(int dtype) { return dtype == FQ_DTYPE_F32 ? 4 : 2; }
-
 struct MaskArgs {
     void* mask = nullptr;
     size_t bytes = 0;

@@ -1,0 +1,320 @@
+// fq_export.h -- the integer side of the fake-quant forward: per-row scale terms and, on request, the
+// packed integer bins the reference rounds to (models/utils_quant.py:71-72  `torch.round(input * s)`; AsymQuantizer
+// :144-146), for inference export and as the pre-pass of the fused QuantizeLinear GEMM.
+//
+//   row_export_kernel          register-resident rows (the row_reg_kernel data flow without the dequantized store):
+//                              read x once (2 B/elem bf16), write bins (1 or 0.5 B/elem, non-temporal) + 8 B/row of
+//                              scales; container = NONE makes it the scale pre-pass (`fq_sym_row_scales`): 2 B/elem read only.
+//   row_export_generic_kernel  any width / alignment (element loads, two sweeps), correctness path.
+//
+// Containers saturate; overflow[row] counts the elements that did not fit (or were NaN).  The reference has no clamp, so
+// in bf16 an 8-bit row can hold the bin +128 (and a 16-bit row bins beyond 32767); the count makes that explicit instead of
+// silently changing a value.  A row whose top bin fits skips the counting entirely (the bin is monotone in |x| / in x).
+#pragma once
+#include "fq_kernels.h"
+
+namespace fq {
+
+enum : int { BINS_NONE = 0, BINS_INT4 = 1, BINS_INT8 = 2, BINS_INT16 = 3 };
+
+struct ExportArgs {
+    const void* x;
+    void* bins;          // packed bins, row stride = export_row_bytes(cols, container); NULL with BINS_NONE
+    float* scales;       // [rows][2]: Sym {s, t2 = s + 1e-6};  Asym {alpha + 1e-8, beta}
+    int32_t* overflow;   // [rows] elements saturated by the container (optional)
+    float* bounds;       // optional [rows][2], as row_reg_kernel
+    uint64_t* mask;      // optional STE bit mask, row_reg_kernel's layout
+    int64_t mask_row_words;
+    float lo, hi;
+    int64_t rows, cols;
+    int64_t row_bytes;   // bins row stride in bytes
+    SymConst sym;
+    AsymConst asym;
+    int container;
+    int autocast;        // Sym on 16-bit tensors: the reference's arithmetic under CUDA autocast (fp32 behind the reciprocal)
+    float cmin, cmax;    // container range as floats: Sym signed [-2^(b-1), 2^(b-1)-1], Asym unsigned [0, 2^b - 1]
+};
+
+__host__ __device__ inline int64_t export_row_bytes(int64_t cols, int container) {
+    return container == BINS_INT4 ? (cols + 1) / 2 : container == BINS_INT8 ? cols : container == BINS_INT16 ? cols * 2 : 0;
+}
+
+// bin value (an integer-valued float, possibly NaN / Inf) -> saturated integer; `bad` = it did not fit
+__device__ __forceinline__ int sat_bin(float q, float cmin, float cmax, bool& bad) {
+    bad = !(q >= cmin && q <= cmax);  // true for NaN
+    if (q != q) return 0;
+    return (int)__builtin_fminf(__builtin_fmaxf(q, cmin), cmax);
+}
+
+// the row's top bin: Sym rint(rb(m * s)) for m = max|x| (the chain is odd and monotone), Asym the bin of the max element
+template <int DT> __device__ __forceinline__ float sym_top_bin(float m, const SymRow& r, bool autocast) {
+    return autocast ? __builtin_rintf(m * r.s) : __builtin_rintf(Ty<DT>::rb(m * r.s));
+}
+template <int DT> __device__ __forceinline__ float asym_bin(float x, const AsymRow& r, const AsymConst& k) {
+    using T = Ty<DT>;
+    const float d = T::rb(x - r.mn);
+    const float n = T::rb(r.mk ? div_exact(d, r.a, r.ra) : d / r.a);
+    return __builtin_rintf(T::rb(n * k.S));
+}
+template <int DT> __device__ __forceinline__ float sym_bin(float x, const SymRow& r, bool autocast) {
+    return autocast ? __builtin_rintf(x * r.s) : __builtin_rintf(Ty<DT>::rb(x * r.s));
+}
+
+template <int DT, int TPR, int VPT, bool ASYM, bool NTL>
+__global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(ExportArgs a) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    constexpr int NW = TPR / 64;
+    __shared__ uint32_t red[3][NW > 1 ? NW : 1];
+    __shared__ uint32_t cnt_lds[NW > 1 ? NW : 1];
+
+    int64_t row;
+    int t;
+    if constexpr (TPR == 64) {
+        row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        t = threadIdx.x & 63;
+        if (row >= a.rows) return;  // wave-uniform; NW == 1: no barrier below
+    } else {
+        row = blockIdx.x;
+        t = threadIdx.x;
+    }
+    const int nvec = (int)(a.cols / EPV);
+    const uint4* __restrict__ xr = (const uint4*)((const char*)a.x + row * a.cols * T::ESIZE);
+    uint4 r[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        int v = t + i * TPR;
+        v = v < nvec ? v : nvec - 1;
+        r[i] = ld16<NTL>(&xr[v]);
+    }
+
+    SymRow sr;
+    AsymRow ar;
+    float ub, lb, top;
+    const bool ac = a.autocast != 0;
+    if constexpr (!ASYM) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            acc = T::absmax_acc(acc, r[i].x);
+            acc = T::absmax_acc(acc, r[i].y);
+            acc = T::absmax_acc(acc, r[i].z);
+            acc = T::absmax_acc(acc, r[i].w);
+        }
+        const float m = as_f(block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]));
+        sr = ac ? sym_row_autocast<DT>(m, a.sym.qmax) : sym_row<DT>(m, a.sym);
+        ub = m;
+        lb = -m;
+        top = sym_top_bin<DT>(m, sr, ac);
+        if (t == 0 && a.scales) {
+            a.scales[2 * row] = sr.s;
+            a.scales[2 * row + 1] = sr.t2;
+        }
+    } else {
+        MinMax mm;
+        {
+            float f0[T::EPD];
+            T::unpack(r[0].x, f0);
+            mm.mx = mm.mn = f0[0];
+            mm.absacc = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            minmax_acc<DT>(mm, r[i].x);
+            minmax_acc<DT>(mm, r[i].y);
+            minmax_acc<DT>(mm, r[i].z);
+            minmax_acc<DT>(mm, r[i].w);
+        }
+        uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
+        block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
+        float mx = as_f(umx), mn = as_f(umn);
+        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);
+        ar = asym_row<DT>(mx, mn, a.asym);
+        ub = mx;
+        lb = mn;
+        top = asym_bin<DT>(mx, ar, a.asym);
+        if (t == 0 && a.scales) {
+            a.scales[2 * row] = ar.a;
+            a.scales[2 * row + 1] = ar.mn;
+        }
+    }
+    if (t == 0 && a.bounds) {
+        a.bounds[2 * row] = ub;
+        a.bounds[2 * row + 1] = lb;
+    }
+
+    const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
+    const bool sym_clip = a.lo == -a.hi;
+    uint64_t* mrow = a.mask + row * a.mask_row_words;
+    const int cont = a.container;
+    // Sym: only the positive side can exceed a signed container whose top bin is cmax + 1 (-128 fits int8, +128 does not)
+    const bool count = cont != BINS_NONE && !(top <= a.cmax);  // block-uniform; true for a NaN row
+    if (cont == BINS_NONE && !want_mask) {
+        if (t == 0 && a.overflow) a.overflow[row] = 0;
+        return;  // the scale pre-pass: nothing elementwise to do
+    }
+    char* brow = (char*)a.bins + row * a.row_bytes;
+    uint32_t nbad = 0;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = t + i * TPR;
+        const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        float f[EPV];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float fd[T::EPD];
+            T::unpack(w[d], fd);
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
+        }
+        if (want_mask && (v - (t & 63) < nvec)) {
+            const int vc = v < nvec ? v : nvec - 1;
+            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(vc >> 6) * EPV;
+            if (sym_clip) ste_mask_store<EPV, true>(f, a.lo, a.hi, gw, t & 63);
+            else ste_mask_store<EPV, false>(f, a.lo, a.hi, gw, t & 63);
+        }
+        if (cont == BINS_NONE) continue;
+        int q[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
+            bool bad;
+            q[e] = sat_bin(b, a.cmin, a.cmax, bad);
+            if (count) nbad += (uint32_t)__popcll(__ballot(bad && v < nvec));
+        }
+        if (v < nvec) {
+            if (cont == BINS_INT8) {
+                uint32_t o[EPV / 4];
+#pragma unroll
+                for (int d = 0; d < EPV / 4; ++d)
+                    o[d] = (uint32_t)(q[4 * d] & 0xFF) | ((uint32_t)(q[4 * d + 1] & 0xFF) << 8) | ((uint32_t)(q[4 * d + 2] & 0xFF) << 16) |
+                           ((uint32_t)(q[4 * d + 3] & 0xFF) << 24);
+                if constexpr (EPV == 8) st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
+                else __builtin_nontemporal_store(o[0], (uint32_t*)brow + v);
+            } else if (cont == BINS_INT4) {
+                uint32_t o = 0;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o |= (uint32_t)(q[e] & 0xF) << (4 * e);
+                if constexpr (EPV == 8) __builtin_nontemporal_store(o, (uint32_t*)brow + v);
+                else __builtin_nontemporal_store((uint16_t)o, (uint16_t*)brow + v);
+            } else {  // BINS_INT16
+                uint32_t o[EPV / 2];
+#pragma unroll
+                for (int d = 0; d < EPV / 2; ++d) o[d] = (uint32_t)(q[2 * d] & 0xFFFF) | ((uint32_t)(q[2 * d + 1] & 0xFFFF) << 16);
+                if constexpr (EPV == 8) st16<true>((uint4*)brow + v, make_uint4(o[0], o[1], o[2], o[3]));
+                else st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
+            }
+        }
+    }
+    if (a.overflow) {
+        if (!count) {
+            if (t == 0) a.overflow[row] = 0;
+        } else if constexpr (NW == 1) {
+            if (t == 0) a.overflow[row] = (int32_t)nbad;
+        } else {
+            if ((t & 63) == 0) cnt_lds[t >> 6] = nbad;
+            __syncthreads();  // `count` is block-uniform
+            if (t == 0) {
+                uint32_t s = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) s += cnt_lds[i];
+                a.overflow[row] = (int32_t)s;
+            }
+        }
+    }
+}
+
+// Any width / alignment: 256 threads sweep the row twice (second sweep is cache-hot); each thread packs element PAIRS so
+// that an int4 byte has one writer.  No STE mask on this path (bounds only).
+template <int DT, bool ASYM> __global__ __launch_bounds__(256) void row_export_generic_kernel(ExportArgs a) {
+    using T = Ty<DT>;
+    constexpr int NW = 4;
+    __shared__ uint32_t red[3][NW];
+    __shared__ uint32_t cnt_lds[NW];
+    const int64_t row = blockIdx.x;
+    const int t = threadIdx.x;
+    const int64_t base = row * a.cols, cols = a.cols;
+    const bool ac = a.autocast != 0;
+    SymRow sr;
+    AsymRow ar;
+    float ub, lb;
+    if constexpr (!ASYM) {
+        uint32_t acc = 0;
+        for (int64_t c = t; c < cols; c += 256) {
+            const uint32_t b = as_u(T::load1(a.x, base + c)) & 0x7FFFFFFFu;
+            acc = acc > b ? acc : b;
+        }
+        const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
+        sr = ac ? sym_row_autocast<DT>(m, a.sym.qmax) : sym_row<DT>(m, a.sym);
+        ub = m;
+        lb = -m;
+        if (t == 0 && a.scales) {
+            a.scales[2 * row] = sr.s;
+            a.scales[2 * row + 1] = sr.t2;
+        }
+    } else {
+        const float first = T::load1(a.x, base);
+        float mx = first, mn = first;
+        uint32_t acc = 0;
+        for (int64_t c = t; c < cols; c += 256) {
+            const float v = T::load1(a.x, base + c);
+            mx = __builtin_fmaxf(mx, v);
+            mn = __builtin_fminf(mn, v);
+            const uint32_t b = as_u(v) & 0x7FFFFFFFu;
+            acc = acc > b ? acc : b;
+        }
+        uint32_t nb = acc, umx = as_u(mx), umn = as_u(mn);
+        block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
+        mx = as_f(umx), mn = as_f(umn);
+        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);
+        ar = asym_row<DT>(mx, mn, a.asym);
+        ub = mx;
+        lb = mn;
+        if (t == 0 && a.scales) {
+            a.scales[2 * row] = ar.a;
+            a.scales[2 * row + 1] = ar.mn;
+        }
+    }
+    if (t == 0 && a.bounds) {
+        a.bounds[2 * row] = ub;
+        a.bounds[2 * row + 1] = lb;
+    }
+    const int cont = a.container;
+    uint32_t nbad = 0;
+    if (cont != BINS_NONE) {
+        char* brow = (char*)a.bins + row * a.row_bytes;
+        for (int64_t c = 2 * (int64_t)t; c < cols; c += 512) {
+            int q[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (c + e < cols) {
+                    const float x = T::load1(a.x, base + c + e);
+                    const float b = ASYM ? asym_bin<DT>(x, ar, a.asym) : sym_bin<DT>(x, sr, ac);
+                    bool bad;
+                    q[e] = sat_bin(b, a.cmin, a.cmax, bad);
+                    nbad += bad ? 1u : 0u;
+                }
+            }
+            if (cont == BINS_INT4) {
+                ((uint8_t*)brow)[c >> 1] = (uint8_t)((q[0] & 0xF) | ((q[1] & 0xF) << 4));
+            } else if (cont == BINS_INT8) {
+                ((int8_t*)brow)[c] = (int8_t)q[0];
+                if (c + 1 < cols) ((int8_t*)brow)[c + 1] = (int8_t)q[1];
+            } else {
+                ((int16_t*)brow)[c] = (int16_t)q[0];
+                if (c + 1 < cols) ((int16_t*)brow)[c + 1] = (int16_t)q[1];
+            }
+        }
+    }
+    if (a.overflow) {
+        // per-thread counts -> block sum (ballot-free: counts differ per lane)
+        uint32_t s = nbad;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+        if ((t & 63) == 0) cnt_lds[t >> 6] = s;
+        __syncthreads();
+        if (t == 0) a.overflow[row] = (int32_t)(cnt_lds[0] + cnt_lds[1] + cnt_lds[2] + cnt_lds[3]);
+    }
+}
+
+}  // namespace fq

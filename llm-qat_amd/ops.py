@@ -442,3 +442,121 @@ def ste_backward(grad_output, x, lo, hi, row_bounds=None, rows_cols_hint=None):
             rc = L.fq_ste_bwd(g.data_ptr(), xc.data_ptr(), gx.data_ptr(), g.numel(), float(lo), float(hi), code, _stream(x))
     _lib.check(rc, "ste_backward")
     return gx
+
+
+# ---- the integer side of the forward: packed bins + scales for export, scale pre-pass --------------------
+_CONTAINERS = {"int4": _lib.BINS_INT4, "int8": _lib.BINS_INT8, "int16": _lib.BINS_INT16}
+
+
+class QuantExport:
+    """Result of sym_export / asym_export.
+      bins      packed integer bins: int8 / int16 tensor of the input's shape, or (int4) uint8 [rows, ceil(cols/2)] with
+                element 2k in the low nibble of byte k
+      scales    float32 [rows, 2]: Sym {s, t2 = s + 1e-6};  Asym {a = alpha + 1e-8, beta}
+      overflow  int32 [rows]: elements the container saturated (0 everywhere <=> dequantize() == the fake-quant forward)
+    """
+    __slots__ = ("kind", "bins", "scales", "overflow", "container", "num_bits", "shape", "rows", "cols", "dtype")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def unpacked(self):
+        """bins as an int32 tensor [rows, cols]"""
+        b = self.bins
+        if self.container != "int4":
+            v = b.reshape(self.rows, self.cols).to(torch.int32)
+            return v & 0xFFFF if (self.kind == "asym" and self.container == "int16") else v   # unsigned 16-bit bins
+        lo, hi = (b & 0xF).to(torch.int32), (b >> 4).to(torch.int32)
+        v = torch.stack((lo, hi), dim=-1).reshape(self.rows, -1)[:, : self.cols]
+        return torch.where(v >= 8, v - 16, v) if self.kind == "sym" else v
+
+    def dequantize(self):
+        """the fake-quant forward's value, recomputed from bins + scales with the reference's op order (fp32 tensors ->
+        round to the tensor dtype after every op); bit-identical to SymQuantizer / AsymQuantizer.forward on rows with
+        overflow == 0 (cpu_eager semantics: true divisions)."""
+        q = self.unpacked().to(torch.float32)
+        sc = self.scales
+        dt = self.dtype
+        if self.kind == "sym":
+            y = (q / sc[:, 1:2]).to(dt)
+        else:
+            S = torch.tensor(float(2 ** self.num_bits - 1), device=q.device)  # a tensor divisor: true division (a Python scalar
+            y = (q / S).to(dt).to(torch.float32)                               # would become a multiply by 1/S on the GPU)
+            y = (y * sc[:, 0:1]).to(dt).to(torch.float32)
+            y = (y + sc[:, 1:2]).to(dt)
+        return y.reshape(self.shape)
+
+
+def default_container(kind, num_bits, dtype):
+    """smallest container that is lossless for every input: Sym bins reach +-(qmax + 1) in bf16 at 8 bits (no clamp in
+    the reference), so 8-bit bf16 defaults to int16; ask for "int8" explicitly to get the saturating deployment format."""
+    if kind == "asym":
+        return "int4" if num_bits <= 4 else "int8" if num_bits <= 8 else "int16"
+    if num_bits <= 4:
+        return "int4"
+    if num_bits <= 7 or (num_bits == 8 and dtype != torch.bfloat16):
+        return "int8"
+    return "int16"
+
+
+def _export(kind, x, num_bits, layerwise, container, autocast):
+    what = f"{kind}_export"
+    code = _prep(x, what)
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    if x.numel() == 0:
+        raise RuntimeError(f"{what}: empty tensor")
+    container = container or default_container(kind, num_bits, x.dtype)
+    cc = _CONTAINERS.get(container)
+    if cc is None:
+        raise ValueError(f"{what}: container must be one of {sorted(_CONTAINERS)}, got {container!r}")
+    xc = x if x.is_contiguous() else x.contiguous()
+    L = _lib.lib()
+    nbytes = L.fq_export_bins_bytes(rows, cols, cc)
+    raw = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    scales = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    overflow = torch.empty(rows, dtype=torch.int32, device=x.device)
+    with _DeviceOf(x):
+        if kind == "sym":
+            rc = L.fq_sym_export(xc.data_ptr(), raw.data_ptr(), scales.data_ptr(), overflow.data_ptr(), rows, cols, int(num_bits), cc, code,
+                                 _semantics, 1 if autocast else 0, _stream(x))
+        else:
+            rc = L.fq_asym_export(xc.data_ptr(), raw.data_ptr(), scales.data_ptr(), overflow.data_ptr(), rows, cols, int(num_bits), cc, code,
+                                  _semantics, _stream(x))
+    _lib.check(rc, what)
+    if container == "int8":
+        bins = (raw.view(torch.int8) if kind == "sym" else raw).view(xc.shape)
+    elif container == "int16":
+        bins = raw.view(torch.int16).view(xc.shape)   # Asym 16-bit bins 32768..65535 read as negative int16: use unpacked()
+    else:
+        bins = raw.view(rows, (cols + 1) // 2)
+    return QuantExport(kind=kind, bins=bins, scales=scales, overflow=overflow, container=container, num_bits=int(num_bits),
+                       shape=tuple(xc.shape), rows=rows, cols=cols, dtype=x.dtype)
+
+
+def sym_export(x, num_bits, layerwise=False, container=None, autocast=None):
+    """SymQuantizer's integer bins `torch.round(input * s)` (utils_quant.py:71-72) packed into int4 / int8 / int16 + per-row
+    {s, t2}.  autocast: None = follow torch.is_autocast_enabled (as the forward does), or force True / False."""
+    ac = autocast_active(x) if autocast is None else bool(autocast)
+    return _export("sym", x, num_bits, layerwise, container, ac)
+
+
+def asym_export(x, num_bits, layerwise=False, container=None):
+    """AsymQuantizer's bins `torch.round(input_normalized * s)` (utils_quant.py:144-146), unsigned, + per-row {alpha+1e-8, beta}"""
+    return _export("asym", x, num_bits, layerwise, container, False)
+
+
+def sym_row_scales(x, num_bits, layerwise=False, autocast=None):
+    """per-row {s, t2} of SymQuantizer.forward without the elementwise pass (fq_sym_row_scales) -> float32 [rows, 2]"""
+    code = _prep(x, "sym_row_scales")
+    rows, cols = rows_cols(tuple(x.shape), layerwise)
+    if x.numel() == 0:
+        raise RuntimeError("sym_row_scales: empty tensor")
+    ac = autocast_active(x) if autocast is None else bool(autocast)
+    xc = x if x.is_contiguous() else x.contiguous()
+    scales = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with _DeviceOf(x):
+        rc = _lib.lib().fq_sym_row_scales(xc.data_ptr(), scales.data_ptr(), rows, cols, int(num_bits), code, _semantics, 1 if ac else 0,
+                                          -2.0, 2.0, None, None, 0, _stream(x))
+    _lib.check(rc, "sym_row_scales")
+    return scales

@@ -441,6 +441,14 @@ class QuantizeLinear(nn.Linear):
             _act_store(key, input_, xq)
         return wq, xq
 
+    def export_weight(self, container=None):
+        """The integer form of this layer's fake-quantized weight for an inference export: packed bins (int4 for
+        w_bits <= 4, int8 / int16 above) + per-output-channel {s, t2} (ops.QuantExport; `dequantize()` gives back the
+        value the forward multiplies with, bit for bit where overflow == 0).  Serves the w_bits >= 3 path (:195-201)."""
+        if not 3 <= self.w_bits < 32:
+            raise ValueError(f"export_weight serves 3 <= w_bits < 32 (SymQuantizer weights), this layer has w_bits={self.w_bits}")
+        return ops.sym_export(self.weight.detach(), self.w_bits, self.weight_layerwise, container=container)
+
     def _forward_compiled(self, input_):
         """forward while torch.compile traces: the same kernels as custom ops, no Python-side caches (compiled.py)"""
         if self.w_bits >= 32:

@@ -35,6 +35,8 @@ def lib():
         L.fqo_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32, i32]
         L.fqo_w12_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32]
         L.fqo_sym_fwd_autocast.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32]
+        L.fqo_export.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32]
+        L.fqo_export.restype = ctypes.c_int
         for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version, L.fqo_sym_fwd_autocast):
             f.restype = ctypes.c_int
         _lib = L
@@ -88,6 +90,40 @@ def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
     if rc:
         raise ValueError(f"fqo_asym_fwd rc={rc}")
     return y, idx, alpha, beta
+
+
+CONTAINERS = {"int4": 1, "int8": 2, "int16": 3}
+
+
+def export(kind, x, rows, cols, bits, container, dtype, sem=SEM_CPU, autocast=False):
+    """packed bins (uint8 bytes [rows, row_bytes]), scales float32[rows, 2], overflow int32[rows]"""
+    x = _check(x, dtype)
+    assert x.size == rows * cols
+    row_bytes = {"int4": (cols + 1) // 2, "int8": cols, "int16": cols * 2}[container]
+    bins = np.zeros((rows, row_bytes), np.uint8)
+    scales = np.empty((rows, 2), np.float32)
+    over = np.empty(rows, np.int32)
+    rc = lib().fqo_export(_p(x), _p(bins), _p(scales), _p(over), rows, cols, bits, CONTAINERS[container], DTYPES[dtype], sem,
+                          1 if kind == "asym" else 0, 1 if autocast else 0)
+    if rc:
+        raise ValueError(f"fqo_export rc={rc}")
+    return bins, scales, over
+
+
+def unpack_bins(bins, cols, container, signed):
+    """uint8 [rows, row_bytes] -> int32 [rows, cols]"""
+    b = np.asarray(bins, np.uint8)
+    if container == "int8":
+        v = b.astype(np.int32)
+        return np.where(v >= 128, v - 256, v) if signed else v
+    if container == "int16":
+        v = b[:, 0::2].astype(np.int32) | (b[:, 1::2].astype(np.int32) << 8)
+        return np.where(v >= 32768, v - 65536, v) if signed else v
+    lo, hi = (b & 0xF).astype(np.int32), (b >> 4).astype(np.int32)
+    v = np.empty((b.shape[0], b.shape[1] * 2), np.int32)
+    v[:, 0::2], v[:, 1::2] = lo, hi
+    v = v[:, :cols]
+    return np.where(v >= 8, v - 16, v) if signed else v
 
 
 def ste_bwd(g, x, lo, hi, dtype):

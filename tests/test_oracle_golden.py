@@ -210,3 +210,86 @@ def test_oracle_is_clean_under_asan_ubsan():
         pytest.skip("sanitizer runtime not installed")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "oracle selftest ok" in r.stdout
+
+
+# ---- packed integer export: the oracle's container logic against the reference's own bins ----------------
+def _container_range(container, signed):
+    cb = {"int4": 4, "int8": 8, "int16": 16}[container]
+    return (-(1 << (cb - 1)), (1 << (cb - 1)) - 1) if signed else (0, (1 << cb) - 1)
+
+
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_export_bins_are_the_reference_bins(kind):
+    """Integer work, bit-exact bar: the exported bins equal the `idx` arrays the real reference produced
+    (tests/golden/*_fwd.npz), saturated to the container; overflow counts exactly the elements that did not fit."""
+    G = golden(f"{kind}_fwd.npz")
+    checked = sat_seen = 0
+    for c in G.cases:
+        x, dt, bits = G.arr(c, "x"), c["dtype"], c["bits"]
+        rows, cols = O.rows_cols(c["shape"], c["layerwise"])
+        idx = G.arr(c, "idx").reshape(rows, cols).astype(np.int64)
+        nan = idx == np.iinfo(np.int32).min
+        for container in ("int4", "int8", "int16"):
+            lo, hi = _container_range(container, kind == "sym")
+            bins, scales, over = O.export(kind, x, rows, cols, bits, container, dt)
+            got = O.unpack_bins(bins, cols, container, kind == "sym")
+            want = np.where(nan, 0, np.clip(idx, lo, hi))
+            assert (got == want).all(), f"{c['name']} {container}: bins differ"
+            bad = nan | (idx < lo) | (idx > hi)
+            assert (over == bad.sum(axis=1)).all(), f"{c['name']} {container}: overflow count"
+            sat_seen += int(bad.any())
+            checked += 1
+        if kind == "sym":
+            assert bits_equal(scales[:, 0], to_f32(G.arr(c, "scale"), dt).reshape(-1), "fp32"), f"{c['name']}: s"
+        else:
+            assert bits_equal(scales[:, 1].copy(), np.asarray(O.asym_fwd(x, rows, cols, bits, dt)[3], np.float32), "fp32")
+    assert checked >= 300 and sat_seen > 0
+
+
+def _pos_zero(a, dt):
+    a = np.array(a, copy=True)
+    if dt == "fp32":
+        a[a == 0] = 0.0
+    else:
+        a[(a & 0x7FFF) == 0] = 0
+    return a
+
+
+def test_export_dequant_reproduces_the_forward():
+    """overflow == 0  <=>  bins / t2 (Sym) reproduces the reference's forward output bit for bit"""
+    G = golden("sym_fwd.npz")
+    n = 0
+    for c in G.cases:
+        x, dt, bits = G.arr(c, "x"), c["dtype"], c["bits"]
+        rows, cols = O.rows_cols(c["shape"], c["layerwise"])
+        bins, scales, over = O.export("sym", x, rows, cols, bits, "int16", dt)
+        q = O.unpack_bins(bins, cols, "int16", True).astype(np.float32)
+        y32 = (q / scales[:, 1:2]).astype(np.float32)
+        want = G.arr(c, "y").reshape(rows, cols)
+        ok_rows = over == 0
+        if dt == "fp32":
+            got = y32
+        else:
+            import torch
+            t = torch.from_numpy(y32).to(torch.bfloat16 if dt == "bf16" else torch.float16)
+            got = t.view(torch.int16).numpy().view(np.uint16)
+        # an integer has no -0: the reference's round(-0.3) = -0.0 dequantises to -0.0, the exported bin 0 to +0.0
+        assert bits_equal(_pos_zero(got[ok_rows], dt), _pos_zero(want[ok_rows], dt), dt), c["name"]
+        n += int(ok_rows.sum())
+    assert n > 400
+
+
+def test_export_8bit_bf16_plus_128_is_counted_not_hidden():
+    """the reference has no clamp: an 8-bit bf16 row whose top bin is +128 saturates int8 and says so; -128 fits"""
+    import torch
+    x = torch.tensor([[1.0, -1.0, 0.5, 0.25] * 4], dtype=torch.float32)
+    x[0, 0] = 1.0
+    xb = x.to(torch.bfloat16)
+    xb_np = xb.view(torch.int16).numpy().view(np.uint16)
+    y, idx, s = O.sym_fwd(xb_np, 1, 16, 8, "bf16")
+    bins, scales, over = O.export("sym", xb_np, 1, 16, 8, "int8", "bf16")
+    got = O.unpack_bins(bins, 16, "int8", True)
+    assert (got == np.clip(idx.reshape(1, 16), -128, 127)).all()
+    assert over[0] == int((idx > 127).sum())
+    b16, _, o16 = O.export("sym", xb_np, 1, 16, 8, "int16", "bf16")
+    assert o16[0] == 0 and (O.unpack_bins(b16, 16, "int16", True) == idx.reshape(1, 16)).all()

@@ -264,6 +264,26 @@ int fq_asym_export(const void* x, void* bins_out, float* scales_out, int32_t* ov
 int fq_sym_row_scales(const void* x, float* scales_out, int64_t rows, int64_t cols, int bits, int dtype, int sem, int autocast, float lo,
                       float hi, float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
 
+/*
+ * QuantizeLinear.forward without a backward (eval, or the first pass of a reentrant-checkpointed layer,
+ * models/modeling_llama_quant.py:732-747) with the fake-quant fused into the GEMM's operand loads:
+ *     out[tokens, out] = fq(x)[tokens, in] . fq(W)[out, in]^T        (models/utils_quant.py:195-201, :244-250)
+ * x_scales / w_scales are the per-row {s, t2} of fq_sym_row_scales (float[rows][2]); an operand whose scales pointer is
+ * NULL is multiplied AS IS (e.g. an activation a sibling projection has already fake-quantized).  The staged operand
+ * values are bit-identical to fq_sym_fwd's (autocast = 0) or to fq_sym_fwd_autocast's bf16-rounded result (autocast = 1);
+ * the product accumulates in fp32 on the matrix cores (v_mfma_f32_32x32x16_bf16) and is rounded once to bf16, so it
+ * differs from F.linear only by the order of the fp32 accumulation.
+ *   dtype      FQ_DTYPE_BF16 (operands and result)
+ *   dump_x / dump_w   optional [tokens, in] / [out, in] bf16 buffers that receive the operand tiles exactly as staged
+ *                     for the MFMAs (test hook: compare with fq_sym_fwd)
+ *   ablation   0; 1 / 2 are timing builds of the cost model (1: staging pipeline without MFMAs, 2: LDS reads + MFMAs
+ *              without staging) whose result is garbage
+ * FQ_ERR_UNSUPPORTED unless in_features % 64 == 0, out_features % 4 == 0, x / w 16-byte and out 8-byte aligned.
+ */
+int fq_qlinear_fwd(const void* x, const float* x_scales, const void* w, const float* w_scales, void* out, int64_t tokens,
+                   int64_t in_features, int64_t out_features, int dtype, int autocast, void* dump_x, void* dump_w, int ablation,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,32 +175,52 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         }
         if (cont == BINS_NONE) continue;
         int q[EPV];
+        if (!count) {
+            // Fast path (block-uniform): the row's top bin fits the container, so every bin does and none is NaN.  The
+            // integer comes out of ONE add: p + 1.5 * 2^23 rounds p to an integer (half to even, like torch.round) and
+            // leaves its two's complement in the low mantissa bits (|p| < 2^22 holds for every container).
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
-            bool bad;
-            q[e] = sat_bin(b, a.cmin, a.cmax, bad);
-            if (count) nbad += (uint32_t)__popcll(__ballot(bad && v < nvec));
+            for (int e = 0; e < EPV; ++e) {
+                float p;
+                if constexpr (ASYM) {
+                    const float d = T::rb(f[e] - ar.mn);
+                    const float n = T::rb(ar.mk ? div_exact(d, ar.a, ar.ra) : d / ar.a);
+                    p = T::rb(n * a.asym.S);
+                } else {
+                    p = ac ? f[e] * sr.s : T::rb(f[e] * sr.s);
+                }
+                q[e] = (int)as_u(p + 12582912.0f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
+                bool bad;
+                q[e] = sat_bin(b, a.cmin, a.cmax, bad);
+                nbad += (uint32_t)__popcll(__ballot(bad && v < nvec));
+            }
         }
         if (v < nvec) {
             if (cont == BINS_INT8) {
                 uint32_t o[EPV / 4];
 #pragma unroll
-                for (int d = 0; d < EPV / 4; ++d)
-                    o[d] = (uint32_t)(q[4 * d] & 0xFF) | ((uint32_t)(q[4 * d + 1] & 0xFF) << 8) | ((uint32_t)(q[4 * d + 2] & 0xFF) << 16) |
-                           ((uint32_t)(q[4 * d + 3] & 0xFF) << 24);
+                for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
+                    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * d + 1], (uint32_t)q[4 * d], 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * d + 3], (uint32_t)q[4 * d + 2], 0x04000c0cu);
+                    o[d] = lo | hi;
+                }
                 if constexpr (EPV == 8) st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
                 else __builtin_nontemporal_store(o[0], (uint32_t*)brow + v);
             } else if (cont == BINS_INT4) {
-                uint32_t o = 0;
+                uint32_t o = (uint32_t)q[0] & 0xFu;
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) o |= (uint32_t)(q[e] & 0xF) << (4 * e);
+                for (int e = 1; e < EPV; ++e) o |= ((uint32_t)q[e] & 0xFu) << (4 * e);
                 if constexpr (EPV == 8) __builtin_nontemporal_store(o, (uint32_t*)brow + v);
                 else __builtin_nontemporal_store((uint16_t)o, (uint16_t*)brow + v);
             } else {  // BINS_INT16
                 uint32_t o[EPV / 2];
 #pragma unroll
-                for (int d = 0; d < EPV / 2; ++d) o[d] = (uint32_t)(q[2 * d] & 0xFFFF) | ((uint32_t)(q[2 * d + 1] & 0xFFFF) << 16);
+                for (int d = 0; d < EPV / 2; ++d) o[d] = __builtin_amdgcn_perm((uint32_t)q[2 * d + 1], (uint32_t)q[2 * d], 0x05040100u);
                 if constexpr (EPV == 8) st16<true>((uint4*)brow + v, make_uint4(o[0], o[1], o[2], o[3]));
                 else st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
             }

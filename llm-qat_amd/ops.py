@@ -560,3 +560,42 @@ def sym_row_scales(x, num_bits, layerwise=False, autocast=None):
                                           -2.0, 2.0, None, None, 0, _stream(x))
     _lib.check(rc, "sym_row_scales")
     return scales
+
+
+def qlinear_forward(x, weight, w_bits, a_bits, quantize_x=True, quantize_w=True, autocast=None, dump=False, ablation=0,
+                    x_scales=None, w_scales=None):
+    """QuantizeLinear's no-grad forward with the fake-quant applied while the GEMM loads its operands (fq_qlinear_fwd):
+    out = fq(x) @ fq(weight).T, bf16.  quantize_x / quantize_w = False multiplies that operand as it is (already
+    fake-quantized by a sibling, or w_bits >= 32).  Scale pre-passes (fq_sym_row_scales) run here unless given.
+    -> out, or (out, staged_x, staged_w) with dump=True (the operand tiles exactly as the MFMAs saw them).
+    Returns None when the shape / alignment is not served (the caller uses the unfused path)."""
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or not (x.is_cuda and weight.is_cuda) or weight.dim() != 2:
+        return None
+    k = weight.shape[1]
+    if x.shape[-1] != k or not (x.is_contiguous() and weight.is_contiguous()) or x.numel() == 0:
+        return None
+    n = weight.shape[0]
+    m = x.numel() // k
+    ac = autocast_active(x) if autocast is None else bool(autocast)
+    L = _lib.lib()
+    code = _lib.DTYPE_BF16
+    with _DeviceOf(x):
+        st = _stream(x)
+        if quantize_x and x_scales is None:
+            x_scales = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+            _lib.check(L.fq_sym_row_scales(x.data_ptr(), x_scales.data_ptr(), m, k, int(a_bits), code, _semantics, 1 if ac else 0, -2.0, 2.0,
+                                           None, None, 0, st), "sym_row_scales")
+        if quantize_w and w_scales is None:
+            w_scales = torch.empty((n, 2), dtype=torch.float32, device=x.device)
+            _lib.check(L.fq_sym_row_scales(weight.data_ptr(), w_scales.data_ptr(), n, k, int(w_bits), code, _semantics, 1 if ac else 0, -2.0, 2.0,
+                                           None, None, 0, st), "sym_row_scales")
+        out = torch.empty(x.shape[:-1] + (n,), dtype=torch.bfloat16, device=x.device)
+        dx = torch.empty_like(x) if dump else None
+        dw = torch.empty_like(weight) if dump else None
+        rc = L.fq_qlinear_fwd(x.data_ptr(), x_scales.data_ptr() if quantize_x else None, weight.data_ptr(), w_scales.data_ptr() if quantize_w else None,
+                              out.data_ptr(), m, k, n, code, 1 if ac else 0, dx.data_ptr() if dump else None, dw.data_ptr() if dump else None,
+                              int(ablation), st)
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "qlinear_forward")
+    return (out, dx, dw) if dump else out

@@ -1,0 +1,94 @@
+"""GPU tier: SURVEY §8 f4a -- fq_qlinear_fwd, QuantizeLinear's no-grad forward with the fake-quant fused into the GEMM's
+operand loads.
+  * the MFMA path itself on exact integer data (asymmetric operands, tails in every dimension): bit-exact vs fp32 matmul
+  * the operand tiles as staged for the MFMAs, dumped: bit-identical to fq_sym_fwd / fq_sym_fwd_autocast(narrow)
+  * the product: within the stated fp32-accumulation tolerance of the exact product of those operands, and of
+    F.linear(fq(x), fq(W)) as the unfused path computes it
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import llm_qat_amd
+    from llm_qat_amd import _lib
+    _lib.lib()
+    llm_qat_amd.set_semantics("cpu_eager")
+    return llm_qat_amd.ops
+
+
+SHAPES = [(256, 128, 64), (300, 388, 192), (1, 4, 64), (513, 260, 640), (2048, 512, 1024)]   # (tokens, out, in)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_mfma_path_exact_on_integer_data(ops, shape):
+    """values in {-2..2}: every partial sum is an exact small integer, so ANY accumulation order gives the same bits; a
+    swapped row/column map, a wrong k-order inside a fragment or a wrong swizzle would not.  Asymmetric operands."""
+    m, n, k = shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randint(-2, 3, (m, k), generator=g, device="cuda").to(torch.bfloat16)
+    w = torch.randint(-2, 3, (n, k), generator=g, device="cuda").to(torch.bfloat16)
+    w[:, 0] = 1
+    x[0, :] = 2      # asymmetric: a row of x and a column of W stand out
+    out = ops.qlinear_forward(x, w, 8, 8, quantize_x=False, quantize_w=False, autocast=False)
+    assert out is not None and out.shape == (m, n)
+    want = (x.float() @ w.float().t())
+    assert want.abs().max() <= 256 * 16
+    assert torch.equal(out.float(), want.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_staged_tiles_are_bit_identical_to_the_quantizer(ops, shape, autocast):
+    m, n, k = shape
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(m, k, generator=g, device="cuda")
+    x[torch.rand(m, k, generator=g, device="cuda") < 1e-3] *= 20
+    x = x.to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    out, sx, sw = ops.qlinear_forward(x, w, 4, 8, autocast=autocast, dump=True)
+    if autocast:
+        xq = ops.sym_forward_autocast(x, 8, False, wide=False)[0]
+        wq = ops.sym_forward_autocast(w, 4, False, wide=False)[0]
+    else:
+        xq, wq = ops.sym_quantize(x, 8), ops.sym_quantize(w, 4)
+    assert torch.equal(sx.view(torch.int16), xq.view(torch.int16)), "staged x tiles != fq_sym_fwd(x)"
+    assert torch.equal(sw.view(torch.int16), wq.view(torch.int16)), "staged W tiles != fq_sym_fwd(W)"
+    # the product of exactly those operands.  Tolerance: the result is the fp32-accumulated sum rounded once to bf16;
+    # against the fp64 product that is <= 2^-9 relative (half a bf16 ulp) + the fp32 accumulation error
+    # (<= K * 2^-24 * sum|a_i b_i|)
+    ref = xq.double() @ wq.double().t()
+    mag = xq.double().abs() @ wq.double().abs().t()
+    tol = ref.abs() * 2.0 ** -8 + mag * k * 2.0 ** -24 + 1e-30
+    assert ((out.double() - ref).abs() <= tol).all(), float(((out.double() - ref).abs() / tol).max())
+    # and the unfused path's own product of the same operands (hipBLASLt, its own accumulation order): <= 1 bf16 ulp apart
+    unf = F.linear(xq, wq)
+    assert ((out.double() - unf.double()).abs() <= ref.abs() * 2.0 ** -7 + mag * k * 2.0 ** -23 + 1e-30).all()
+    # mixed: only W quantized on load, x handed over already quantized == both on load, bit for bit (same staged values)
+    out2 = ops.qlinear_forward(xq, w, 4, 8, quantize_x=False, autocast=autocast)
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+
+
+def test_llama7b_shape_full_size(ops):
+    """[2048, 11008] x [4096, 11008]^T, W4 A8 (down_proj): staged operands bit-identical; the product a bf16 ulp from hipBLASLt's"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2048, 11008, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(4096, 11008, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    out, sx, sw = ops.qlinear_forward(x, w, 4, 8, autocast=False, dump=True)
+    xq, wq = ops.sym_quantize(x, 8), ops.sym_quantize(w, 4)
+    assert torch.equal(sx.view(torch.int16), xq.view(torch.int16)) and torch.equal(sw.view(torch.int16), wq.view(torch.int16))
+    unf = F.linear(xq, wq).float()
+    err = (out.float() - unf).abs()
+    scale = unf.abs().mean()
+    assert float(err.max()) <= float(unf.abs().max()) * 2.0 ** -6 and float(err.mean()) <= float(scale) * 2.0 ** -8
+
+
+def test_unserved_shapes_return_none(ops):
+    x = torch.randn(8, 100, device="cuda").to(torch.bfloat16)
+    w = torch.randn(16, 100, device="cuda").to(torch.bfloat16)
+    assert ops.qlinear_forward(x, w, 4, 8) is None                       # in_features % 64 != 0
+    assert ops.qlinear_forward(x.float(), w.float(), 4, 8) is None       # bf16 only

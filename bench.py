@@ -860,7 +860,64 @@ def export_entries(wl, iters):
     return {"kernels_export": [roofline_entry(k, b, wl.time_kernel(fn, iters)) for k, fn, b in ks]}
 
 
-EXTRA_ENTRIES = [export_entries]
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def qlinear_entries(wl, iters):
+    """SURVEY §8 f4a on its named shape: QuantizeLinear's no-grad forward for down_proj, x[2048,11008] . W[4096,11008]^T, W4 A8 --
+    the unfused product path (one fq pair launch + F.linear / hipBLASLt) beside fq_qlinear_fwd (fake-quant applied in the
+    GEMM's operand staging).  Roofline of the fused kernel: MFMA (dense bf16 peak)."""
+    import torch.nn.functional as F
+    torch, L, lib_, st = wl.torch, wl.L, wl._lib, wl.stream
+    m, k, n = 2048, wl.cols, wl.rows
+    code = lib_.DTYPE_BF16
+    sets = []
+    for s in wl.sets[:3]:
+        x = s["a"][:m]
+        sets.append(dict(w=s["w"], x=x, wq=s["yw"], xq=s["ya"][:m], o=torch.empty(m, n, dtype=torch.bfloat16, device=wl.device),
+                         ws=torch.empty(n, 2, device=wl.device), xs=torch.empty(m, 2, device=wl.device)))
+
+    def chk(rc):
+        if rc:
+            lib_.check(rc, "qlinear")
+
+    def pair(s):
+        chk(L.fq_sym_fwd_pair(s["w"].data_ptr(), s["wq"].data_ptr(), n, 4, None, None, 0, s["x"].data_ptr(), s["xq"].data_ptr(), m, 8, None, None, 0,
+                              k, code, 0, 0, -2.0, 2.0, st))
+
+    def quant_x(s):
+        chk(L.fq_sym_fwd(s["x"].data_ptr(), s["xq"].data_ptr(), m, k, 8, code, 0, None, None, 0, st))
+
+    def scales(s, key, rows, bits):
+        chk(L.fq_sym_row_scales(s[key].data_ptr(), s[key + "s"].data_ptr(), rows, k, bits, code, 0, 0, -2.0, 2.0, None, None, 0, st))
+
+    def kern(s, qa, qw):
+        chk(L.fq_qlinear_fwd((s["x"] if qa else s["xq"]).data_ptr(), s["xs"].data_ptr() if qa else None, (s["w"] if qw else s["wq"]).data_ptr(),
+                             s["ws"].data_ptr() if qw else None, s["o"].data_ptr(), m, k, n, code, 0, None, None, 0, st))
+
+    for s in sets:
+        pair(s), scales(s, "w", n, 4), scales(s, "x", m, 8)
+    flops = 2.0 * m * k * n
+    kinds = [
+        ("unfused (product default): fq pair launch + F.linear (hipBLASLt)", lambda s: (pair(s), F.linear(s["xq"], s["wq"]))),
+        ("unfused: F.linear alone", lambda s: F.linear(s["xq"], s["wq"])),
+        ("qlinear_fused: fq_sym_fwd(x) + row scales(W) + fq_qlinear_fwd(W quantized on load)", lambda s: (quant_x(s), scales(s, "w", n, 4), kern(s, 0, 1))),
+        ("qlinear_fused kernel alone, W on load", lambda s: kern(s, 0, 1)),
+        ("qlinear_fused kernel alone, W + x on load", lambda s: kern(s, 1, 1)),
+        ("qlinear_fused kernel alone, nothing quantized (its raw GEMM)", lambda s: kern(s, 0, 0)),
+    ]
+    out = []
+    for name, fn in kinds:
+        ms, pct = time_launches(torch, fn, max(10, iters // 4), sets)
+        tf = flops / (ms * 1e-3) / 1e12
+        out.append({"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                    "us_per_launch": round(ms * 1e3, 2), "us_p10_p50_p90": [round(v * 1e3, 2) for v in pct], "flops": flops, "traffic": None})
+    return {"qlinear_down_proj": {"shape": f"x[{m},{k}] . W[{n},{k}]^T, W4 A8, bf16, no-grad forward", "entries": out,
+                                  "verdict": "unfused wins: the staged fake-quant is re-done once per tile that shares the operand (W: tokens/256 = 8x, "
+                                             "x: out/128 = 32x) and does not hide under the MFMAs; see DESIGN.md §10"}}
+
+
+EXTRA_ENTRIES = [export_entries, qlinear_entries]
 
 
 if __name__ == "__main__":

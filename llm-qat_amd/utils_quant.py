@@ -273,6 +273,21 @@ def pair_operands(flag=True):
     _PAIR = bool(flag)
 
 
+# 4. (opt-in) When no backward will run -- eval, or the first pass of a reentrant-checkpointed layer
+#    (modeling_llama_quant.py:732-747) -- the weight's fake-quant can be applied inside the GEMM's operand staging
+#    (fq_qlinear_fwd) instead of writing the quantized weight to HBM first.  MEASURED SLOWER than the default on MI355X
+#    (profiles/r02_qlinear_bench*.json, DESIGN.md §10: the staged fake-quant is re-done by every tile that shares the
+#    operand and does not hide under the MFMAs; hipBLASLt's GEMM is also faster than this kernel's), so it is OFF by
+#    default: LLMQAT_AMD_FUSED_QLINEAR=1 / fuse_qlinear(True) turn it on.  Operand values are bit-identical either way;
+#    the product differs by fp32 accumulation order only.
+_FUSED_QLINEAR = os.environ.get("LLMQAT_AMD_FUSED_QLINEAR", "0") == "1"
+
+
+def fuse_qlinear(flag=True):
+    global _FUSED_QLINEAR
+    _FUSED_QLINEAR = bool(flag)
+
+
 class _PairNode(torch.autograd.Function):
     """Autograd node over the results of one ops.pair_forward launch (weight and input of a QuantizeLinear)."""
 
@@ -441,6 +456,28 @@ class QuantizeLinear(nn.Linear):
             _act_store(key, input_, xq)
         return wq, xq
 
+    def _fused_forward(self, input_):
+        """no-grad forward through fq_qlinear_fwd (weight quantized on load); None when not applicable"""
+        w = self.weight
+        if not (3 <= self.w_bits < 32 and w.is_cuda and w.dtype == torch.bfloat16 and input_.dtype == torch.bfloat16 and not self.weight_layerwise):
+            return None
+        ac = ops.autocast_active(w)
+        if ac and not ops.autocast_narrow_ok(w):
+            return None
+        if 2 < self.a_bits < 32:
+            if self.act_quantizer is not SymQuantizer:
+                return None
+            x = _shared_activation(self.act_quantizer, input_, self.a_bits, self.act_layerwise)  # once per sibling group, standalone
+        else:
+            x = input_
+        if x.dtype != torch.bfloat16 or not x.is_contiguous():
+            return None
+        key = (id(w), w._version, w.data_ptr(), self.w_bits, ops.get_semantics(), ac)
+        ent = getattr(self, "_fq_wscales", None)
+        if ent is None or ent[0] != key:  # the row scales change only when the weight does (optimizer step)
+            ent = self._fq_wscales = (key, ops.sym_row_scales(w, self.w_bits, False, autocast=ac))
+        return ops.qlinear_forward(x, w, self.w_bits, self.a_bits, quantize_x=False, quantize_w=True, autocast=ac, w_scales=ent[1])
+
     def export_weight(self, container=None):
         """The integer form of this layer's fake-quantized weight for an inference export: packed bins (int4 for
         w_bits <= 4, int8 / int16 above) + per-output-channel {s, t2} (ops.QuantExport; `dequantize()` gives back the
@@ -471,6 +508,10 @@ class QuantizeLinear(nn.Linear):
         assert len(self.weight.size()) == 2
         if torch.compiler.is_compiling():
             return self._forward_compiled(input_)
+        if _FUSED_QLINEAR and not (torch.is_grad_enabled() and (self.weight.requires_grad or input_.requires_grad)):
+            out = self._fused_forward(input_)
+            if out is not None:
+                return out
         pair = self._pair_forward(input_)
         if pair is not None:
             return nn.functional.linear(pair[1], pair[0])

@@ -92,3 +92,47 @@ def test_unserved_shapes_return_none(ops):
     w = torch.randn(16, 100, device="cuda").to(torch.bfloat16)
     assert ops.qlinear_forward(x, w, 4, 8) is None                       # in_features % 64 != 0
     assert ops.qlinear_forward(x.float(), w.float(), 4, 8) is None       # bf16 only
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_module_opt_in_fused_forward(ops, autocast):
+    """QuantizeLinear with fuse_qlinear(True): eval / no-grad forwards take fq_qlinear_fwd (weight quantized on load, the
+    activation quantized once and shared by siblings); training forwards are untouched.  Same operand values, product
+    within a bf16 ulp of the default path's."""
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(4)
+    q, k = (QuantizeLinear(1024, 512, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(2))
+    x = torch.randn(3, 100, 1024, device="cuda").bfloat16()
+    calls = []
+    orig = llm_qat_amd.ops.qlinear_forward
+
+    def spy(*a, **kw):
+        calls.append(1)
+        return orig(*a, **kw)
+
+    llm_qat_amd.ops.qlinear_forward = spy
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            ref = [m(x) for m in (q, k)]
+            llm_qat_amd.fuse_qlinear(True)
+            got = [m(x) for m in (q, k)]
+            assert len(calls) == 2
+            for a, b in zip(got, ref):
+                assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape
+                assert ((a.float() - b.float()).abs() <= b.float().abs() * 2.0 ** -7 + 1e-3).all()
+        # a training forward never takes the fused path
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            q(xg).float().sum().backward()
+        assert len(calls) == 2 and xg.grad is not None and q.weight.grad is not None
+        # weight update -> the cached row scales are recomputed
+        with torch.no_grad():
+            q.weight.mul_(1.5)
+            a = q(x)
+            llm_qat_amd.fuse_qlinear(False)
+            b = q(x)
+        assert ((a.float() - b.float()).abs() <= b.float().abs() * 2.0 ** -7 + 1e-3).all()
+    finally:
+        llm_qat_amd.ops.qlinear_forward = orig
+        llm_qat_amd.fuse_qlinear(False)

@@ -187,6 +187,23 @@ int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* 
                          int64_t cols, float lo, float hi, int dtype, void* stream);
 
 /*
+ * The N-tensor form of the two entry points above (1 <= n <= 4 tensors of one dtype and one row length per launch).  The
+ * attention block quantizes the q/k/v weights [4096, 4096] x 3 and their shared input [tokens, 4096] at the same moment
+ * (models/modeling_llama_quant.py:313,317,318), the MLP its gate/up weights and their input (:235): every tensor reduces over
+ * the same `in`, so one launch (forward) and one (backward) serve the whole sibling group.  Tensor i owns rows
+ * [sum(rows[<i]), +rows[i]) of the launch; results are bit-identical to separate calls.
+ *   fq_fwd_tensor   x, y, rows, bits, optional row_bounds + mask (training mode; a mask needs its row_bounds)
+ *   fq_bwd_tensor   g, gx, rows, row_bounds, mask (all required)
+ *   autocast        as fq_sym_fwd_pair (0 / 1 / 2);  wide_grad = 1: the g are fp32 gradients of fp32 results (autocast = 2
+ *                   forward) and the gx have `dtype`, as fq_ste_bwd_mask_wide
+ * fq_sym_fwd_pair / fq_ste_bwd_mask_pair / fq_ste_bwd_mask_wide are the n = 2 (or 1) forms of these.
+ */
+typedef struct { const void* x; void* y; int64_t rows; int bits; float* row_bounds; void* mask; size_t mask_bytes; } fq_fwd_tensor;
+typedef struct { const void* g; void* gx; int64_t rows; const float* row_bounds; const void* mask; } fq_bwd_tensor;
+int fq_sym_fwd_multi(int n, const fq_fwd_tensor* tensors, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream);
+int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* tensors, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream);
+
+/*
  * STE backward behind a fp32-result forward (fq_sym_fwd_autocast wide_out = 1 / fq_sym_fwd_pair autocast = 2), the
  * reference's `grad_input = grad_output.clone(); grad_input[mask] = 0` (models/utils_quant.py:83-87) followed by the
  * autograd engine's cast of that fp32 gradient to the input's dtype, in one pass:  gx = mask ? 0 : round_to_dtype(g).

@@ -20,8 +20,19 @@ EXPORTS = (
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
     "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
-    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_qlinear_fwd",
+    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_qlinear_fwd", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi",
 )
+MAX_TENSORS = 4  # tensors per multi-tensor launch
+
+
+class FwdTensor(ctypes.Structure):  # fq_fwd_tensor
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("rows", ctypes.c_int64), ("bits", ctypes.c_int), ("row_bounds", ctypes.c_void_p),
+                ("mask", ctypes.c_void_p), ("mask_bytes", ctypes.c_size_t)]
+
+
+class BwdTensor(ctypes.Structure):  # fq_bwd_tensor
+    _fields_ = [("g", ctypes.c_void_p), ("gx", ctypes.c_void_p), ("rows", ctypes.c_int64), ("row_bounds", ctypes.c_void_p), ("mask", ctypes.c_void_p)]
+
 BINS_NONE, BINS_INT4, BINS_INT8, BINS_INT16 = 0, 1, 2, 3
 ERR_UNSUPPORTED = -8
 
@@ -83,6 +94,10 @@ def _bind(L):
     L.fq_sym_row_scales.restype = i32
     L.fq_qlinear_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp]
     L.fq_qlinear_fwd.restype = i32
+    L.fq_sym_fwd_multi.argtypes = [i32, ctypes.POINTER(FwdTensor), i64, i32, i32, i32, f32, f32, vp]
+    L.fq_sym_fwd_multi.restype = i32
+    L.fq_ste_bwd_mask_multi.argtypes = [i32, ctypes.POINTER(BwdTensor), i64, f32, f32, i32, i32, vp]
+    L.fq_ste_bwd_mask_multi.restype = i32
     return L
 
 

@@ -49,7 +49,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, sem);
-    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, nullptr, nullptr, nullptr, nullptr, 0.f};
+    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, 0, {}};
     if (mk) {
         if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
         const int64_t mrw = mask_row_words(cols, esize_of(dtype));
@@ -141,7 +141,7 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, FQ_SEM_DEVICE_EAGER);
-    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, nullptr, nullptr, nullptr, nullptr, 0.f};
+    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, 0, {}};
     if (mask_out) {
         if (!row_bounds_out) return fail(FQ_ERR_NULL, "a mask needs row_bounds_out too");
         const int64_t mrw = mask_row_words(cols, 2);
@@ -157,27 +157,35 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
                                   : launch_sym_autocast<F16>(wide_out != 0, a, workspace, workspace_bytes, st);
 }
 
-FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* row_bounds0, void* mask0, size_t mask_bytes0,
-                           const void* x1, void* y1, int64_t rows1, int bits1, float* row_bounds1, void* mask1, size_t mask_bytes1,
-                           int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
-    if (bits0 < 2 || bits0 > 31 || bits1 < 2 || bits1 > 31) return fail(FQ_ERR_BITS, "num_bits outside [2, 31]");
+    if (n < 1 || n > 1 + MAX_MORE || !t) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (autocast < 0 || autocast > 2) return fail(FQ_ERR_ARG, "autocast must be 0, 1 or 2");
     if (autocast && dtype == FQ_DTYPE_F32) return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
-    if (rows0 <= 0 || rows1 <= 0 || cols <= 0) return fail(FQ_ERR_SHAPE, "pair launch needs two non-empty tensors");
-    if (!x0 || !y0 || !x1 || !y1) return fail(FQ_ERR_NULL, "pair launch: x / y of both tensors required");
-    if ((mask0 && !row_bounds0) || (mask1 && !row_bounds1)) return fail(FQ_ERR_NULL, "a mask needs its row_bounds too");
+    if (cols <= 0) return fail(FQ_ERR_SHAPE, "multi-tensor launch needs non-empty tensors");
     const int64_t mrw = mask_row_words(cols, esize_of(dtype));
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the register kernels (see fq_ste_mask_bytes)");
-    if ((mask0 && mask_bytes0 < (size_t)rows0 * mrw * 8) || (mask1 && mask_bytes1 < (size_t)rows1 * mrw * 8))
-        return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
-    const Consts c0 = make_consts(bits0, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem), c1 = make_consts(bits1, dtype, sem);
-    RowArgs a{x0, y0, nullptr, nullptr, row_bounds0, rows0 + rows1, cols, c0.sym, c0.asym, (uint64_t*)mask0, mrw, host_rb(lo, dtype), host_rb(hi, dtype),
-              rows0, x1, y1, row_bounds1, (uint64_t*)mask1, c1.sym.qmax};
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (t[i].bits < 2 || t[i].bits > 31) return fail(FQ_ERR_BITS, "num_bits outside [2, 31]");
+        if (t[i].rows <= 0) return fail(FQ_ERR_SHAPE, "multi-tensor launch needs non-empty tensors");
+        if (!t[i].x || !t[i].y) return fail(FQ_ERR_NULL, "multi-tensor launch: x / y of every tensor required");
+        if (t[i].mask && !t[i].row_bounds) return fail(FQ_ERR_NULL, "a mask needs its row_bounds too");
+        if (t[i].mask && t[i].mask_bytes < (size_t)t[i].rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
+        total += t[i].rows;
+    }
+    const Consts c0 = make_consts(t[0].bits, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem);
+    RowArgs a{t[0].x, t[0].y, nullptr, nullptr, t[0].row_bounds, total, cols, c0.sym, c0.asym, (uint64_t*)t[0].mask, mrw, host_rb(lo, dtype),
+              host_rb(hi, dtype), t[0].rows, n - 1, {}};
+    int64_t begin = t[0].rows;
+    for (int i = 1; i < n; ++i) {
+        a.more[i - 1] = TensorSlot{begin, t[i].x, t[i].y, t[i].row_bounds, (uint64_t*)t[i].mask, make_consts(t[i].bits, dtype, sem).sym.qmax};
+        begin += t[i].rows;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (autocast) {
-        const bool wide = autocast == 2;  // y0 / y1 are fp32; masks (if any) in the wide layout, for fq_ste_bwd_mask_wide
+        const bool wide = autocast == 2;  // the y are fp32; masks (if any) in the wide layout, for fq_ste_bwd_mask_wide
         return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide, a, nullptr, 0, st) : launch_sym_autocast<F16>(wide, a, nullptr, 0, st);
     }
     switch (dtype) {
@@ -187,22 +195,54 @@ FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, f
     }
 }
 
+FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* row_bounds0, void* mask0, size_t mask_bytes0,
+                           const void* x1, void* y1, int64_t rows1, int bits1, float* row_bounds1, void* mask1, size_t mask_bytes1,
+                           int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+    const fq_fwd_tensor t[2] = {{x0, y0, rows0, bits0, row_bounds0, mask0, mask_bytes0}, {x1, y1, rows1, bits1, row_bounds1, mask1, mask_bytes1}};
+    return fq_sym_fwd_multi(2, t, cols, dtype, sem, autocast, lo, hi, stream);
+}
+
+FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (wide_grad && dtype == FQ_DTYPE_F32) return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward: the input dtype must be bf16 / fp16");
+    if (n < 1 || n > 1 + MAX_MORE || !t) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
+    if (cols <= 0) return fail(FQ_ERR_SHAPE, "multi-tensor launch needs non-empty tensors");
+    if (!mask_row_words(cols, esize_of(dtype))) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path");
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (t[i].rows <= 0) return fail(FQ_ERR_SHAPE, "multi-tensor launch needs non-empty tensors");
+        if (!t[i].g || !t[i].gx || !t[i].row_bounds || !t[i].mask) return fail(FQ_ERR_NULL, "multi-tensor launch: all buffers required");
+        total += t[i].rows;
+    }
+    lo = host_rb(lo, dtype);
+    hi = host_rb(hi, dtype);
+    SteMore m{};
+    m.rows0 = t[0].rows;
+    m.n = n - 1;
+    int64_t begin = t[0].rows;
+    for (int i = 1; i < n; ++i) {
+        m.t[i - 1] = SteSlot{begin, t[i].g, t[i].gx, t[i].row_bounds, (const uint64_t*)t[i].mask};
+        begin += t[i].rows;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const SteMore* mp = n > 1 ? &m : nullptr;
+    const float* b0 = t[0].row_bounds;
+    const uint64_t* m0 = (const uint64_t*)t[0].mask;
+    if (wide_grad)
+        return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp)
+                                      : launch_ste_mask_wide<F16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_ste_mask<F32>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+        case FQ_DTYPE_F16: return launch_ste_mask<F16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+        default: return launch_ste_mask<BF16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+    }
+}
+
 FQ_API int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
                                 const void* g1, void* gx1, int64_t rows1, const float* row_bounds1, const void* mask1,
                                 int64_t cols, float lo, float hi, int dtype, void* stream) {
-    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
-    if (rows0 <= 0 || rows1 <= 0 || cols <= 0) return fail(FQ_ERR_SHAPE, "pair launch needs two non-empty tensors");
-    if (!g0 || !gx0 || !g1 || !gx1 || !row_bounds0 || !row_bounds1 || !mask0 || !mask1) return fail(FQ_ERR_NULL, "pair launch: all buffers required");
-    if (!mask_row_words(cols, esize_of(dtype))) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path");
-    lo = host_rb(lo, dtype);
-    hi = host_rb(hi, dtype);
-    hipStream_t st = (hipStream_t)stream;
-    const SteSecond sec{rows0, g1, gx1, row_bounds1, (const uint64_t*)mask1};
-    switch (dtype) {
-        case FQ_DTYPE_F32: return launch_ste_mask<F32>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
-        case FQ_DTYPE_F16: return launch_ste_mask<F16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
-        default: return launch_ste_mask<BF16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, &sec);
-    }
+    const fq_bwd_tensor t[2] = {{g0, gx0, rows0, row_bounds0, mask0}, {g1, gx1, rows1, row_bounds1, mask1}};
+    return fq_ste_bwd_mask_multi(2, t, cols, lo, hi, dtype, 0, stream);
 }
 
 FQ_API int fq_ste_bwd_mask_wide(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
@@ -210,19 +250,10 @@ FQ_API int fq_ste_bwd_mask_wide(const void* g0, void* gx0, int64_t rows0, const 
                                 int64_t cols, float lo, float hi, int dtype, void* stream) {
     if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16) return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward: the input dtype must be bf16 / fp16");
     if (rows0 < 0 || rows1 < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
-    if (rows0 == 0 && rows1 == 0) return ok();
-    if (cols == 0) return ok();
+    if ((rows0 == 0 && rows1 == 0) || cols == 0) return ok();
     if (rows0 == 0) return fail(FQ_ERR_SHAPE, "a single tensor goes first (rows1 = 0)");
-    if (!g0 || !gx0 || !row_bounds0 || !mask0) return fail(FQ_ERR_NULL, "g / gx / row_bounds / mask must not be NULL");
-    if (rows1 && (!g1 || !gx1 || !row_bounds1 || !mask1)) return fail(FQ_ERR_NULL, "second tensor: all buffers required");
-    if (!mask_row_words(cols, 2)) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
-    lo = host_rb(lo, dtype);
-    hi = host_rb(hi, dtype);
-    hipStream_t st = (hipStream_t)stream;
-    const SteSecond sec{rows0, g1, gx1, row_bounds1, (const uint64_t*)mask1};
-    const SteSecond* sp = rows1 ? &sec : nullptr;
-    return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, sp)
-                                  : launch_ste_mask_wide<F16>(g0, gx0, rows0 + rows1, cols, lo, hi, row_bounds0, (const uint64_t*)mask0, st, sp);
+    const fq_bwd_tensor t[2] = {{g0, gx0, rows0, row_bounds0, mask0}, {g1, gx1, rows1, row_bounds1, mask1}};
+    return fq_ste_bwd_mask_multi(rows1 ? 2 : 1, t, cols, lo, hi, dtype, 1, stream);
 }
 
 FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* row_bounds,

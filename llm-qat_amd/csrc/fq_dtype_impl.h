@@ -56,7 +56,7 @@ template <int DT, int TPR, bool NTL, bool NTS>
 static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
     const int64_t grid = TPR == 64 ? (a.rows + 3) / 4 : a.rows;
     constexpr int BLOCK = TPR == 64 ? 256 : TPR;
-    const bool mask = a.mask || a.mask1;  // the mask-recording code lives in its own instantiation (it costs the plain one 7 %)
+    const bool mask = any_mask(a);  // the mask-recording code lives in its own instantiation (it costs the plain one 7 %)
     switch (hpt) {
 #define H(N)                                                                                            \
     case N:                                                                                             \
@@ -77,17 +77,17 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
     } else {
         constexpr int EPV = 8;
-        const bool pair = a.x1 != nullptr;
-        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && (!pair || (aligned16(a.x1) && aligned16(a.y1)));
+        const bool pair = a.n_more > 0;
+        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u);
         const int64_t nvec = a.cols / EPV;
-        const int64_t big_rows = pair ? (a.rows0 > a.rows - a.rows0 ? a.rows0 : a.rows - a.rows0) : a.rows;
+        const int64_t big_rows = largest_rows(a);
         const int64_t bytes = big_rows * a.cols * T::ESIZE;
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
         if constexpr (AC == 2) {
             // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced
             const int64_t nh = a.cols / 4;
             const bool wide_ok = aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8 &&
-                                 (!pair || (aligned16(a.y1) && (reinterpret_cast<uintptr_t>(a.x1) & 7u) == 0));
+                                 more_aligned(a, 7u, 15u);
             if (wide_ok) {
                 const bool nts = 3 * bytes >= NT_STORE_MIN_BYTES, ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define W(TPR)                                                                                          \
@@ -150,10 +150,10 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
     clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
-    const bool pair = a.x1 != nullptr;  // two tensors in one launch: register kernels only
-    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && (!pair || (aligned16(a.x1) && aligned16(a.y1)));
+    const bool pair = a.n_more > 0;  // several tensors in one launch: register kernels only
+    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u);
     const int64_t nvec = a.cols / EPV;
-    const int64_t big_rows = pair ? (a.rows0 > a.rows - a.rows0 ? a.rows0 : a.rows - a.rows0) : a.rows;
+    const int64_t big_rows = largest_rows(a);
     const int64_t bytes = big_rows * a.cols * T::ESIZE;  // cache policy follows the larger tensor
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
     bool two_pass = false, two_pass_vec = false;
@@ -257,21 +257,24 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
 
 template <int DT>
 int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
-                    hipStream_t st, const SteSecond* second) {
+                    hipStream_t st, const SteMore* more) {
     using T = Ty<DT>;
     clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw || !(aligned16(g) && aligned16(gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape/alignment not served");
-    if (second && !(aligned16(second->g) && aligned16(second->gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served");
-    const SteSecond sec = second ? *second : SteSecond{rows, nullptr, nullptr, nullptr, nullptr};
+    SteMore sec{};
+    sec.rows0 = rows;
+    if (more) sec = *more;
+    for (int i = 0; i < sec.n; ++i)
+        if (!(aligned16(sec.t[i].g) && aligned16(sec.t[i].gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served");
     const int64_t nvec_row = cols / EPV;
     const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
     int cv = (int)((nvec_row + chunks - 1) / chunks);
     cv = (cv + 63) / 64 * 64;  // every wave covers exactly one 64-vector mask group per slot
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
     if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-    const int64_t big_rows = second ? (sec.rows0 > rows - sec.rows0 ? sec.rows0 : rows - sec.rows0) : rows;
+    const int64_t big_rows = largest_rows(sec, rows);
     const int64_t bytes = big_rows * cols * T::ESIZE;
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
 #define S(V)                                                                                                                                         \
@@ -287,7 +290,7 @@ int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
 
 template <int DT>
 int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
-                         hipStream_t st, const SteSecond* second) {
+                         hipStream_t st, const SteMore* more) {
     using T = Ty<DT>;
     clear_stale_error();
     if constexpr (T::ESIZE != 2) {
@@ -296,15 +299,18 @@ int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, fl
         const int64_t mrw = mask_row_words(cols, T::ESIZE);
         auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
         if (!mrw || cols > 32768 || !(aligned16(g) && al8(gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: shape/alignment not served");
-        if (second && !(aligned16(second->g) && al8(second->gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
-        const SteSecond sec = second ? *second : SteSecond{rows, nullptr, nullptr, nullptr, nullptr};
+        SteMore sec{};
+        sec.rows0 = rows;
+        if (more) sec = *more;
+        for (int i = 0; i < sec.n; ++i)
+            if (!(aligned16(sec.t[i].g) && al8(sec.t[i].gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
         const int64_t nh_row = cols / 4;
         const int64_t chunks = (nh_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
         int ch = (int)((nh_row + chunks - 1) / chunks);
         ch = (ch + 63) / 64 * 64;  // every wave covers exactly one 64-half-vector mask group per slot
         const int hpt = (ch + STE_THREADS - 1) / STE_THREADS;
         if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-        const int64_t big_rows = second ? (sec.rows0 > rows - sec.rows0 ? sec.rows0 : rows - sec.rows0) : rows;
+        const int64_t big_rows = largest_rows(sec, rows);
         const int64_t bytes = big_rows * cols * 4;  // the fp32 gradient is the larger stream
         const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= 2 * NT_STORE_MIN_BYTES;
 #define S(V)                                                                                                                                           \
@@ -344,8 +350,8 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
-    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteSecond*); \
-    template int launch_ste_mask_wide<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteSecond*); \
+    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
+    template int launch_ste_mask_wide<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 
 }  // namespace fq

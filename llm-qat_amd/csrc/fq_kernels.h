@@ -17,6 +17,16 @@
 
 namespace fq {
 
+constexpr int MAX_MORE = 3;  // up to 4 tensors per launch (q/k/v weights + their shared input)
+struct TensorSlot {
+    int64_t row_begin;
+    const void* x;
+    void* y;
+    float* bounds;
+    uint64_t* mask;
+    float qmax;
+};
+
 struct RowArgs {
     const void* x;
     void* y;
@@ -33,16 +43,14 @@ struct RowArgs {
     uint64_t* mask;
     int64_t mask_row_words;
     float lo, hi;
-    // optional SECOND tensor of the same launch (register-resident Sym kernels only): same dtype and cols (so the same
-    // launch shape), its own rows / bit width / outputs.  QuantizeLinear needs its weight [out, in] and its input
-    // [tokens, in] fake-quantized at the same moment and both reduce over `in`: one launch instead of two saves the
-    // ~2.8 us launch boundary.  Rows [0, rows0) belong to the first tensor, [rows0, rows) to the second.
+    // optional FURTHER tensors of the same launch (register-resident Sym kernels only): same dtype and cols (so the same
+    // launch shape), each with its own rows / bit width / outputs.  QuantizeLinear needs its weight [out, in] and its input
+    // [tokens, in] fake-quantized at the same moment and both reduce over `in`; sibling projections (q/k/v, gate/up) add
+    // their weights: one launch instead of up to four saves ~2.8 us of launch boundary each.  Rows [0, rows0) belong to
+    // the first tensor, rows [more[i].row_begin, next begin) to further tensor i.
     int64_t rows0;
-    const void* x1;
-    void* y1;
-    float* bounds1;
-    uint64_t* mask1;
-    float qmax1;
+    int n_more;
+    TensorSlot more[MAX_MORE];
 };
 
 // STE bit mask layout (private to the forward/backward kernel pair, independent of launch shape):
@@ -139,12 +147,19 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     uint64_t* msk = a.mask;
     SymConst symk = a.sym;
     if (row >= a.rows0) {
-        row -= a.rows0;
-        xb = a.x1;
-        yb = a.y1;
-        bnd = a.bounds1;
-        msk = a.mask1;
-        symk.qmax = a.qmax1;
+        int64_t rbase = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_MORE; ++i) {  // static indices: scalar selects, the slots stay in SGPRs / kernarg loads
+            if (i < a.n_more && row >= a.more[i].row_begin) {
+                rbase = a.more[i].row_begin;
+                xb = a.more[i].x;
+                yb = a.more[i].y;
+                bnd = a.more[i].bounds;
+                msk = a.more[i].mask;
+                symk.qmax = a.more[i].qmax;
+            }
+        }
+        row -= rbase;
     }
     const int nvec = (int)(a.cols / EPV);
     const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row * a.cols * T::ESIZE);
@@ -328,12 +343,19 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
     uint64_t* msk = a.mask;
     float qmax = a.sym.qmax;
     if (row >= a.rows0) {
-        row -= a.rows0;
-        xb = a.x1;
-        yb = a.y1;
-        bnd = a.bounds1;
-        msk = a.mask1;
-        qmax = a.qmax1;
+        int64_t rbase = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_MORE; ++i) {
+            if (i < a.n_more && row >= a.more[i].row_begin) {
+                rbase = a.more[i].row_begin;
+                xb = a.more[i].x;
+                yb = a.more[i].y;
+                bnd = a.more[i].bounds;
+                msk = a.more[i].mask;
+                qmax = a.more[i].qmax;
+            }
+        }
+        row -= rbase;
     }
     const int nh = (int)(a.cols / 4);
     const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row * a.cols * 2);
@@ -848,28 +870,40 @@ __device__ __forceinline__ void ste_mask_wide_slots(const uint4 (&rg)[HPT], uint
     }
 }
 
-struct SteSecond {  // optional second tensor of a mask-backward launch (same dtype and cols; see RowArgs)
-    int64_t rows0;
+struct SteSlot {
+    int64_t row_begin;
     const void* g;
     void* gx;
     const float* bounds;
     const uint64_t* mask;
+};
+struct SteMore {  // optional further tensors of a mask-backward launch (same dtype and cols; see RowArgs)
+    int64_t rows0;  // rows of the first tensor (= all rows of the launch when n == 0)
+    int n;
+    SteSlot t[MAX_MORE];
 };
 
 template <int DT, int VPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nvec_row,
                                                                int64_t chunks, int cv, const float* __restrict__ bounds,
                                                                const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
-                                                               float hi, SteSecond second) {
+                                                               float hi, SteMore more) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
     int64_t row = blockIdx.x / chunks;
-    if (row >= second.rows0) {  // block-uniform
-        row -= second.rows0;
-        g = second.g;
-        gx = second.gx;
-        bounds = second.bounds;
-        mask = second.mask;
+    if (row >= more.rows0) {  // block-uniform
+        int64_t rbase = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_MORE; ++i) {
+            if (i < more.n && row >= more.t[i].row_begin) {
+                rbase = more.t[i].row_begin;
+                g = more.t[i].g;
+                gx = more.t[i].gx;
+                bounds = more.t[i].bounds;
+                mask = more.t[i].mask;
+            }
+        }
+        row -= rbase;
     }
     const int64_t vs = (blockIdx.x % chunks) * cv;
     const int64_t off = row * nvec_row + vs;
@@ -907,16 +941,23 @@ template <int DT, int HPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nh_row,
                                                                     int64_t chunks, int ch, const float* __restrict__ bounds,
                                                                     const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
-                                                                    float hi, SteSecond second) {
+                                                                    float hi, SteMore more) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "fp32 gradient in, 16-bit gradient out");
     int64_t row = blockIdx.x / chunks;
-    if (row >= second.rows0) {  // block-uniform
-        row -= second.rows0;
-        g = second.g;
-        gx = second.gx;
-        bounds = second.bounds;
-        mask = second.mask;
+    if (row >= more.rows0) {  // block-uniform
+        int64_t rbase = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_MORE; ++i) {
+            if (i < more.n && row >= more.t[i].row_begin) {
+                rbase = more.t[i].row_begin;
+                g = more.t[i].g;
+                gx = more.t[i].gx;
+                bounds = more.t[i].bounds;
+                mask = more.t[i].mask;
+            }
+        }
+        row -= rbase;
     }
     const int64_t hs = (blockIdx.x % chunks) * ch;
     const int64_t off = row * nh_row + hs;

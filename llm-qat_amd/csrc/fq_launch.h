@@ -28,6 +28,36 @@ inline int launch_result() {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// the further tensors of a multi-tensor launch: alignment of their x / y, and the rows of the largest tensor (its size
+// decides the cache policy of the launch)
+inline bool more_aligned(const RowArgs& a, uintptr_t xmask, uintptr_t ymask) {
+    for (int i = 0; i < a.n_more; ++i)
+        if ((reinterpret_cast<uintptr_t>(a.more[i].x) & xmask) || (reinterpret_cast<uintptr_t>(a.more[i].y) & ymask)) return false;
+    return true;
+}
+inline bool any_mask(const RowArgs& a) {
+    bool m = a.mask != nullptr;
+    for (int i = 0; i < a.n_more; ++i) m = m || a.more[i].mask;
+    return m;
+}
+inline int64_t largest_rows(const RowArgs& a) {
+    if (!a.n_more) return a.rows;
+    int64_t big = a.rows0;
+    for (int i = 0; i < a.n_more; ++i) {
+        const int64_t end = i + 1 < a.n_more ? a.more[i + 1].row_begin : a.rows;
+        if (end - a.more[i].row_begin > big) big = end - a.more[i].row_begin;
+    }
+    return big;
+}
+inline int64_t largest_rows(const SteMore& m, int64_t rows) {
+    if (!m.n) return rows;
+    int64_t big = m.rows0;
+    for (int i = 0; i < m.n; ++i) {
+        const int64_t end = i + 1 < m.n ? m.t[i + 1].row_begin : rows;
+        if (end - m.t[i].row_begin > big) big = end - m.t[i].row_begin;
+    }
+    return big;
+}
 
 // Cache policy of the 16-byte streams, from tools/kbench on MI355X (every tensor is touched once per launch):
 //  * stores: non-temporal from 4 MiB up (a tensor that size cannot stay in an XCD's 4 MiB L2 anyway).  NT stores
@@ -115,11 +145,11 @@ template <int DT> FQ_HIDDEN int launch_sym_autocast(bool wide, RowArgs a, void* 
 template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
 template <int DT>
 FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                              const uint64_t* mask, hipStream_t st, const SteSecond* second = nullptr);
+                              const uint64_t* mask, hipStream_t st, const SteMore* more = nullptr);
 // STE backward of a fp32-result forward: g is fp32, gx has the (16-bit) dtype DT; mask in the wide forward's layout
 template <int DT>
 FQ_HIDDEN int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                                   const uint64_t* mask, hipStream_t st, const SteSecond* second = nullptr);
+                                   const uint64_t* mask, hipStream_t st, const SteMore* more = nullptr);
 template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);

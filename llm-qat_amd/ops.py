@@ -348,6 +348,74 @@ def pair_backward_wide(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, out
     return ow, ox
 
 
+def multi_forward(tensors, bits, need, lo, hi):
+    """2..4 tensors with the same row length, dtype and device in ONE launch (fq_sym_fwd_multi): a QuantizeLinear's weight
+    and input plus the weights of the sibling projections that share that input (q/k/v, gate/up).
+    tensors / bits / need: parallel lists (need[i]: record bounds + STE mask for tensor i's backward).
+    -> ([y_i], [side_i or None], [rows_i], cols) or None when the group is not served."""
+    n = len(tensors)
+    t0 = tensors[0]
+    if not 2 <= n <= _lib.MAX_TENSORS or not t0.is_cuda:
+        return None
+    code = _DTYPES.get(t0.dtype)
+    cols = t0.shape[-1]
+    if code is None:
+        return None
+    rows, mbytes = [], []
+    for t in tensors:
+        if t.dtype != t0.dtype or t.device != t0.device or not t.is_contiguous() or not 1 <= t.dim() <= 3 or t.shape[-1] != cols or t.numel() == 0:
+            return None
+        r = t.numel() // cols
+        mb = _mask_bytes(r, cols, code)
+        if not mb:
+            return None
+        rows.append(r)
+        mbytes.append(mb)
+    ac = autocast_active(t0)
+    if ac and not autocast_narrow_ok(t0):
+        return None
+    ys = [torch.empty_like(t) for t in tensors]
+    sides = [torch.empty(r * 8 + mb, dtype=torch.uint8, device=t0.device) if nd else None for r, mb, nd in zip(rows, mbytes, need)]
+    arr = (_lib.FwdTensor * n)()
+    for i, (t, y, sd) in enumerate(zip(tensors, ys, sides)):
+        sp = sd.data_ptr() if sd is not None else None
+        arr[i] = _lib.FwdTensor(t.data_ptr(), y.data_ptr(), rows[i], int(bits[i]), sp, sp + rows[i] * 8 if sp else None, mbytes[i] if sp else 0)
+    with _DeviceOf(t0):
+        rc = _lib.lib().fq_sym_fwd_multi(n, arr, cols, code, _semantics, 1 if ac else 0, float(lo), float(hi), _stream(t0))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "quantize_multi")
+    return ys, sides, rows, cols
+
+
+def multi_backward(grads, sides, rows, cols, lo, hi):
+    """STE backward of the tensors of a multi_forward in one launch; grads[i] may be None (that tensor is skipped)."""
+    live = [i for i, g in enumerate(grads) if g is not None]
+    out = [None] * len(grads)
+    if not live:
+        return out
+    if len(live) == 1:
+        i = live[0]
+        out[i] = train_backward(grads[i], sides[i], rows[i], cols, lo, hi)
+        return out
+    code = _DTYPES.get(grads[live[0]].dtype)
+    gs = {i: _aligned(grads[i]) for i in live}
+    arr = (_lib.BwdTensor * len(live))()
+    for j, i in enumerate(live):
+        out[i] = torch.empty_like(gs[i])
+        sp = sides[i].data_ptr()
+        arr[j] = _lib.BwdTensor(gs[i].data_ptr(), out[i].data_ptr(), rows[i], sp, sp + rows[i] * 8)
+    g0 = gs[live[0]]
+    with _DeviceOf(g0):
+        rc = _lib.lib().fq_ste_bwd_mask_multi(len(live), arr, cols, float(lo), float(hi), code, 0, _stream(g0))
+    if rc == _lib.ERR_UNSUPPORTED:
+        for i in live:
+            out[i] = train_backward(gs[i], sides[i], rows[i], cols, lo, hi)
+        return out
+    _lib.check(rc, "quantize_multi_backward")
+    return out
+
+
 def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     """Training-mode forward (fq_*_fwd_train): -> (y, row_bounds, mask) or None if this shape/alignment is
     not served by the STE-mask path (the caller then uses the general forward + x-based backward).

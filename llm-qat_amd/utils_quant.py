@@ -226,17 +226,17 @@ def _act_key(quantizer, x, num_bits, layerwise):
     return (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(x))
 
 
-def _act_lookup(key, x):
+def _act_lookup(key, x, want_leader=False):
     cache = getattr(_tls, "act", None)
     ent = cache.get(key) if cache else None
     if ent is not None:
-        rin, ver_in, y, ver_out, epoch = ent
+        rin, ver_in, y, ver_out, epoch, leader = ent
         if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0]:
-            return y
-    return None
+            return (y, leader() if leader is not None else None) if want_leader else y
+    return (None, None) if want_leader else None
 
 
-def _act_store(key, x, y):
+def _act_store(key, x, y, leader=None):
     cache = getattr(_tls, "act", None)
     if cache is None:
         cache = _tls.act = {}
@@ -246,7 +246,7 @@ def _act_store(key, x, y):
         if ent is not None and ent[0] is ref:
             del cache[key]
 
-    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0])
+    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0], weakref.ref(leader) if leader is not None else None)
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
@@ -328,6 +328,52 @@ class _PairNode(torch.autograd.Function):
         return ow, ox, None, None
 
 
+# 5. Sibling projections share their input (q/k/v: modeling_llama_quant.py:313,317,318; gate/up: :235) and all reduce over
+#    the same `in`: the first of them to run (the "leader") quantizes its weight, the shared input AND the siblings'
+#    weights in ONE launch (fq_sym_fwd_multi, up to 4 tensors), and one backward launch returns all their gradients
+#    (autograd runs a node once every output's gradient has arrived).  Siblings are learned, not declared: a module that
+#    finds its activation already quantized by another module registers with that module, and is served from the next
+#    forward on.  A prefetched weight is used only if the weight is still the very tensor (identity, version, storage) it
+#    was computed from, in the same grad / autocast / backward mode, with no fake-quant backward in between.
+_GROUP = os.environ.get("LLMQAT_AMD_GROUP_SIBLINGS", "1") != "0"
+_MAX_FOLLOWERS = 2
+
+
+def group_siblings(flag=True):
+    global _GROUP
+    _GROUP = bool(flag)
+
+
+class _MultiNode(torch.autograd.Function):
+    """Autograd node over the results of one ops.multi_forward launch."""
+
+    @staticmethod
+    def forward(ctx, res, clip, *tensors):
+        ys, sides, ctx.rows, ctx.cols = res
+        ctx.dtype, ctx.clip = tensors[0].dtype, clip
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*sides)
+        outs = tuple(y.view_as(y) for y in ys)
+        nd = [o for o, need in zip(outs, ctx.needs_input_grad[2:]) if not need]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        _bwd_epoch[0] += 1
+        lo, hi = ctx.clip
+        gs = []
+        for g, need in zip(grads, ctx.needs_input_grad[2:]):
+            if g is None or not need:
+                gs.append(None)
+            else:
+                gs.append(g if g.dtype == ctx.dtype else g.to(ctx.dtype))
+        outs = ops.multi_backward(gs, list(ctx.saved_tensors), ctx.rows, ctx.cols, lo, hi)
+        return (None, None) + tuple(outs)
+
+
 def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
     """The two KV-cache hooks of the attention block (models/modeling_llama_quant.py:320-327),
 
@@ -399,8 +445,16 @@ class QuantizeLinear(nn.Linear):
             sc = absmean if self.w_bits == 1 else 2 * absmean
         return _LowBitWeight.apply(w, sc, self.w_bits)
 
+    def _prefetch_key(self):
+        w = self.weight
+        return (id(w), w._version, w.data_ptr(), self.w_bits, torch.is_grad_enabled() and w.requires_grad, _BACKWARD_MODE, ops.get_semantics(),
+                ops.autocast_active(w), _bwd_epoch[0])
+
     def _quantized_weight(self):
         w = self.weight
+        pre = self.__dict__.pop("_fq_prefetch", None)
+        if pre is not None and pre[0] == self._prefetch_key():
+            return pre[1]  # the leader of this sibling group quantized this weight in its own launch
         if not _WEIGHT_CACHE or not w.is_cuda:
             return _SymQuantizerOperand.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         ac = ops.autocast_active(w)
@@ -441,9 +495,20 @@ class QuantizeLinear(nn.Linear):
         if self.act_quantizer is not SymQuantizer or self.act_layerwise or self.weight_layerwise:
             return None
         key = _act_key(_SymQuantizerOperand, input_, self.a_bits, False) if _SHARE_ACT else None
-        if key is not None and _act_lookup(key, input_) is not None:
-            return None  # a sibling projection already quantized this activation: only the weight is left to do
+        if key is not None:
+            y, leader = _act_lookup(key, input_, want_leader=True)
+            if y is not None:
+                # a sibling projection already quantized this activation: only the weight is left to do -- and next time
+                # that sibling (the leader) does this weight too, in its own launch
+                if _GROUP and leader is not None and leader is not self:
+                    fl = leader.__dict__.setdefault("_fq_followers", [])
+                    if len(fl) < _MAX_FOLLOWERS and all(r() is not self for r in fl):
+                        fl.append(weakref.ref(self))
+                return None
         grad = torch.is_grad_enabled()
+        multi = self._multi_forward(input_, key, grad) if (_GROUP and key is not None and self.__dict__.get("_fq_followers")) else None
+        if multi is not None:
+            return multi
         res = ops.pair_forward(self.weight, input_, self.w_bits, self.a_bits, -2.0, 2.0,
                                grad and self.weight.requires_grad, grad and input_.requires_grad)
         if res is None:
@@ -453,8 +518,34 @@ class QuantizeLinear(nn.Linear):
         else:
             wq, xq = res[0], res[1]
         if key is not None:
-            _act_store(key, input_, xq)
+            _act_store(key, input_, xq, leader=self)
         return wq, xq
+
+    def _multi_forward(self, input_, key, grad):
+        """this module's weight + the shared input + the weights of the sibling projections that registered as followers,
+        one launch (ops.multi_forward); the followers find their quantized weight in `_fq_prefetch`.  None: not served."""
+        w = self.weight
+        fols = []
+        for r in self._fq_followers:
+            f = r()
+            if (f is not None and 3 <= f.w_bits < 32 and f.a_bits == self.a_bits and not f.weight_layerwise and not f.act_layerwise
+                    and getattr(f, "act_quantizer", None) is SymQuantizer and f.weight.dtype == w.dtype and f.weight.device == w.device
+                    and f.weight.dim() == 2 and f.weight.shape[1] == w.shape[1] and f.weight.is_contiguous()):
+                fols.append(f)
+        self._fq_followers = [weakref.ref(f) for f in fols]  # dead or changed siblings drop out
+        if not fols:
+            return None
+        tensors = [w, input_] + [f.weight for f in fols]
+        bits = [self.w_bits, self.a_bits] + [f.w_bits for f in fols]
+        need = [grad and w.requires_grad, grad and input_.requires_grad] + [grad and f.weight.requires_grad for f in fols]
+        res = ops.multi_forward(tensors, bits, need, -2.0, 2.0)
+        if res is None:
+            return None
+        outs = _MultiNode.apply(res, (-2.0, 2.0), *tensors) if any(need) else tuple(res[0])
+        for f, o in zip(fols, outs[2:]):
+            f._fq_prefetch = (f._prefetch_key(), o)
+        _act_store(key, input_, outs[1], leader=self)
+        return outs[0], outs[1]
 
     def _fused_forward(self, input_):
         """no-grad forward through fq_qlinear_fwd (weight quantized on load); None when not applicable"""

@@ -733,3 +733,88 @@ def test_autocast_dtype_differs_from_tensor_dtype(pkg):
             want = F.linear(sym(x, 8), sym(lin.weight, 4))
         assert got.dtype == want.dtype == adt
         assert torch.equal(got, want), (tdt, adt, (got.float() - want.float()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------ N-tensor launches
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_multi_tensor_launch_matches_separate_calls(pkg, dtype):
+    """fq_sym_fwd_multi / fq_ste_bwd_mask_multi on 2, 3 and 4 tensors of one row length (q/k/v weights + their shared
+    input): values, side buffers' effect and gradients bit-identical to one call per tensor."""
+    ops = pkg.ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cols = 1024
+    mk = lambda rows, sc: (torch.randn(rows, cols, generator=g, device="cuda") * sc).to(TD[dtype])  # noqa: E731
+    tensors = [mk(384, 0.02), mk(3 * 50, 1.3).view(3, 50, cols), mk(256, 0.02), mk(512, 0.9)]
+    tensors[3][5, 7] = 2.5
+    bits = [4, 8, 4, 3]
+    for n in (2, 3, 4):
+        ts, bs = tensors[:n], bits[:n]
+        res = ops.multi_forward(ts, bs, [True] * n, -2.0, 2.0)
+        assert res is not None
+        ys, sides, rows, c = res
+        grads = [torch.randn_like(t) for t in ts]
+        gxs = ops.multi_backward(grads, sides, rows, c, -2.0, 2.0)
+        for t, b, y, gr, gx in zip(ts, bs, ys, grads, gxs):
+            y1, s1, r1, c1 = ops.train_forward("sym", t, b, False, -2.0, 2.0)
+            assert torch.equal(y.view(torch.uint8), y1.view(torch.uint8))
+            assert torch.equal(gx.view(torch.uint8), ops.train_backward(gr, s1, r1, c1, -2.0, 2.0).view(torch.uint8))
+        # a subset of the gradients (the others None): only those are produced
+        part = ops.multi_backward([grads[0]] + [None] * (n - 1), sides, rows, c, -2.0, 2.0)
+        assert part[1] is None and torch.equal(part[0], gxs[0])
+    # a tensor that needs no backward gets no side buffer
+    ys, sides, rows, c = ops.multi_forward(tensors[:3], bits[:3], [True, False, True], -2.0, 2.0)
+    assert sides[1] is None and sides[0] is not None
+    # not served: different row lengths / dtypes / too many tensors -> None (the caller falls back to separate calls)
+    assert ops.multi_forward([tensors[0], tensors[0][:, :512].contiguous()], [4, 4], [False, False], -2.0, 2.0) is None
+    assert ops.multi_forward(tensors + [tensors[0]], bits + [4], [False] * 5, -2.0, 2.0) is None
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_sibling_projections_share_one_launch(pkg, autocast):
+    """q/k/v-style siblings: from the second forward on the leader quantizes its weight, the shared input and both
+    siblings' weights in ONE launch and one backward launch returns the four gradients -- bit-identical to the ungrouped
+    flow across training steps (weights change between steps), in eval, and when a sibling's weight changes between the
+    leader's launch and its own forward."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(0)
+    names = ["multi_forward", "multi_backward", "pair_forward", "pair_backward", "train_forward", "train_backward", "sym_forward_autocast"]
+
+    def run(group):
+        torch.manual_seed(1)
+        mods = [QuantizeLinear(1024, 768, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(3)]
+        opt = torch.optim.SGD([m.weight for m in mods], lr=0.05)
+        pkg.group_siblings(group)
+        log = []
+        try:
+            for step in range(3):
+                x = (torch.randn(2, 64, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + step)) * 1.5).bfloat16().requires_grad_(True)
+                opt.zero_grad(set_to_none=True)
+                with Counter(pkg.ops, names) as c:
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                        loss = qkv_loss(mods, x)
+                    loss.backward()
+                log.append((loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n))
+                opt.step()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                xe = (torch.randn(2, 64, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(99)) * 1.5).bfloat16()
+                ev = [m(xe) for m in mods]
+                # a sibling's weight changes after the leader prefetched it: the stale prefetch must not be used
+                o0 = mods[0](xe)
+                mods[1].weight.mul_(2.0)
+                o1 = mods[1](xe)
+            log.append((ev, o0, o1))
+        finally:
+            pkg.group_siblings(True)
+        return log
+
+    a, b = run(True), run(False)
+    for s in range(3):
+        assert torch.equal(a[s][0], b[s][0]) and torch.equal(a[s][1], b[s][1]), f"step {s}"
+        for ga, gb in zip(a[s][2], b[s][2]):
+            assert torch.equal(ga, gb), f"step {s}"
+    for ea, eb in zip(a[3][0], b[3][0]):
+        assert torch.equal(ea, eb)
+    assert torch.equal(a[3][1], b[3][1]) and torch.equal(a[3][2], b[3][2])
+    # launches per step: ungrouped 1 pair + 2 weights forward, the same backward = 6; grouped (from step 1 on) 1 + 1
+    assert b[0][3] == 6 and b[2][3] == 6, (b[0][3], b[2][3])
+    assert a[0][3] == 6 and a[1][3] == 2 and a[2][3] == 2, (a[0][3], a[1][3], a[2][3])

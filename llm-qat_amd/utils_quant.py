@@ -502,8 +502,8 @@ class QuantizeLinear(nn.Linear):
                 # that sibling (the leader) does this weight too, in its own launch
                 if _GROUP and leader is not None and leader is not self:
                     fl = leader.__dict__.setdefault("_fq_followers", [])
-                    if len(fl) < _MAX_FOLLOWERS and all(r() is not self for r in fl):
-                        fl.append(weakref.ref(self))
+                    if len(fl) < _MAX_FOLLOWERS and all(r() is not self for r, _ in fl):
+                        fl.append((weakref.ref(self), leader.weight._version))
                 return None
         grad = torch.is_grad_enabled()
         multi = self._multi_forward(input_, key, grad) if (_GROUP and key is not None and self.__dict__.get("_fq_followers")) else None
@@ -525,14 +525,23 @@ class QuantizeLinear(nn.Linear):
         """this module's weight + the shared input + the weights of the sibling projections that registered as followers,
         one launch (ops.multi_forward); the followers find their quantized weight in `_fq_prefetch`.  None: not served."""
         w = self.weight
-        fols = []
-        for r in self._fq_followers:
+        fols, keep = [], []
+        for r, reg_version in self._fq_followers:
             f = r()
-            if (f is not None and 3 <= f.w_bits < 32 and f.a_bits == self.a_bits and not f.weight_layerwise and not f.act_layerwise
+            if f is None:
+                continue
+            keep.append((r, reg_version))
+            # A group learned during a forward becomes active in grad mode only once the leader's weight has changed since
+            # (an optimizer step lies in between): a checkpointed forward and its recompute must build the same graph, so
+            # the switch from "pair + separate weights" to "one launch" may not fall between the two.  Without grad there
+            # is no graph: active at once.
+            if grad and w._version == reg_version:
+                continue
+            if (3 <= f.w_bits < 32 and f.a_bits == self.a_bits and not f.weight_layerwise and not f.act_layerwise
                     and getattr(f, "act_quantizer", None) is SymQuantizer and f.weight.dtype == w.dtype and f.weight.device == w.device
                     and f.weight.dim() == 2 and f.weight.shape[1] == w.shape[1] and f.weight.is_contiguous()):
                 fols.append(f)
-        self._fq_followers = [weakref.ref(f) for f in fols]  # dead or changed siblings drop out
+        self._fq_followers = keep  # dead siblings drop out
         if not fols:
             return None
         tensors = [w, input_] + [f.weight for f in fols]

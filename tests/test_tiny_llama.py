@@ -163,3 +163,49 @@ def test_dropin_with_kv_hooks_in_one_launch(autocast):
     finally:
         TL.KV_ONE_LAUNCH = False
         llm_qat_amd.set_semantics("cpu_eager")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reentrant", [True, False])
+def test_training_steps_with_sibling_grouping_match_eager_chain(reentrant):
+    """Several optimizer steps of run_train.sh's combination (bf16 autocast + per-layer activation checkpointing).  From
+    the second step on the drop-in serves q/k/v and gate/up sibling groups with ONE launch each (learned in step one,
+    active once the weights have changed): every step's loss and every parameter after every step stay bit-identical to
+    the eager chain -- and a checkpointed forward and its recompute always build the same graph."""
+    from torch.utils.checkpoint import checkpoint
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+
+    def train(model, steps=3):
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = model.model.embed_tokens(ids)
+                h.requires_grad_(True)
+                for layer in model.model.layers:
+                    h = checkpoint(layer, h, use_reentrant=reentrant)
+                logits = model.lm_head(model.model.norm(h))
+                loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), ids[..., 1:].reshape(-1))
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    ref = TL.load_deterministic(TL.TinyLlama(TL.EagerQuant(), w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+    ours = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+    calls = []
+    orig = llm_qat_amd.ops.multi_forward
+    llm_qat_amd.ops.multi_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        l_ref, p_ref = train(ref)
+        l, p = train(ours)
+    finally:
+        llm_qat_amd.ops.multi_forward = orig
+    assert len(calls) > 0, "the sibling groups never became active"
+    for s, (a, b) in enumerate(zip(l, l_ref)):
+        assert torch.equal(a, b), (s, a.item(), b.item())
+    for a, b, (n, _) in zip(p, p_ref, ours.named_parameters()):
+        assert torch.equal(a, b), n

@@ -49,9 +49,11 @@ def step(model, ids, ckpt):
     return loss
 
 
-def timed(fn, iters):
-    for _ in range(2):
-        fn()
+def timed(fn, iters, after_first=None):
+    fn()
+    if after_first is not None:
+        after_first()
+    fn()
     best = float("inf")
     for _ in range(3):  # best of three runs of `iters` steps: one-off stalls (allocator growth, clock ramps) do not count
         torch.cuda.synchronize()
@@ -89,7 +91,8 @@ def main():
     for wb, ab, kvb in ((4, 8, 4), (8, 8, 8))[: 1 if args.only else 2]:
         for ckpt in (False, True)[: 1 if args.only else 2]:
             for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
-                                         ("llm_qat_amd", UQ, False), ("llm_qat_amd + K/V in one launch", UQ, False),
+                                         ("llm_qat_amd", UQ, False), ("llm_qat_amd, sibling groups off", UQ, False),
+                                         ("llm_qat_amd + K/V in one launch", UQ, False),
                                          ("llm_qat_amd + weight cache", UQ, True)):
                 if args.only and label != args.only:
                     continue
@@ -99,9 +102,16 @@ def main():
                 else:
                     model = build(quant, args.layers, wb, ab, kvb)
                 llm_qat_amd.enable_weight_quant_cache(wcache)
+                llm_qat_amd.group_siblings("groups off" not in label)
                 torch.cuda.reset_peak_memory_stats()
                 base = torch.cuda.memory_allocated()   # parameters (+ ids): the step's own peak is reported on top of this
-                ms = timed(lambda: step(model, ids, ckpt), args.iters)
+
+                def touch_weights():   # what an optimizer step does to the version counters: sibling groups learned in the
+                    with torch.no_grad():   # first step become active (llm-qat_amd/utils_quant.py, point 5)
+                        for p in model.parameters():
+                            p.mul_(1.0)
+                ms = timed(lambda: step(model, ids, ckpt), args.iters, touch_weights)
+                llm_qat_amd.group_siblings(True)
                 peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
                 llm_qat_amd.enable_weight_quant_cache(False)
                 rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers, dims=MODEL,

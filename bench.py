@@ -917,7 +917,47 @@ def qlinear_entries(wl, iters):
                                              "x: out/128 = 32x) and does not hide under the MFMAs; see DESIGN.md §10"}}
 
 
-EXTRA_ENTRIES = [export_entries, qlinear_entries]
+def lowbit_asym_entries(wl, iters):
+    """the 1-/2-bit weight branches on [4096,11008] bf16 (utils_quant.py:202-242) -- the default
+    (ATen abs + mean, then fq_w12_fwd: 3 launches) and the opt-in one-launch kernel -- and AsymQuantizer A8 on [2048,11008]."""
+    torch, L, lib_, st = wl.torch, wl.L, wl._lib, wl.stream
+    rows, cols, n = wl.rows, wl.cols, wl.n
+    code = lib_.DTYPE_BF16
+    for s in wl.sets:
+        s.setdefault("sc16", torch.empty(rows, dtype=torch.bfloat16, device=wl.device))
+
+    def chk(rc):
+        if rc:
+            lib_.check(rc, "w12/asym")
+
+    def w12_default(bits):
+        def fn(s):
+            sc = s["w"].abs().mean(dim=1, keepdim=True)
+            if bits == 2:
+                sc = 2 * sc
+            chk(L.fq_w12_fwd(s["w"].data_ptr(), sc.data_ptr(), s["yw"].data_ptr(), rows, cols, bits, 1, code, st))
+        return fn
+
+    def w12_fused(bits):
+        return lambda s: chk(L.fq_w12_fwd_rows(s["w"].data_ptr(), s["yw"].data_ptr(), s["sc16"].data_ptr(), rows, cols, bits, code, 0, st))
+
+    t2 = 2048
+    def asym(s):
+        chk(L.fq_asym_fwd_train(s["a"].data_ptr(), s["ya"].data_ptr(), t2, cols, 8, code, 0, -2.0, 2.0, s["ba"].data_ptr(), s["ma"].data_ptr(), wl.mask_bytes, st))
+
+    ks = [("w12 1-bit default: ATen abs+mean + fq_w12_fwd (3 launches, ~10 B/elem moved)", w12_default(1), n * 4, n * 10),
+          ("w12 2-bit default: ATen abs+mean + fq_w12_fwd (3 launches, ~10 B/elem moved)", w12_default(2), n * 4, n * 10),
+          ("w12 1-bit one launch (opt-in, in-kernel row mean)", w12_fused(1), n * 4, n * 4),
+          ("w12 2-bit one launch (opt-in, in-kernel row mean)", w12_fused(2), n * 4, n * 4),
+          ("asym_fwd_a8 bf16 [2048,11008] (training mode)", asym, t2 * cols * 4, t2 * cols * 4 + t2 * cols // 8)]
+    out = []
+    for k, fn, algo, moved in ks:
+        e = roofline_entry(k, algo, wl.time_kernel(fn, iters), moved_bytes=moved)
+        out.append(e)
+    return {"kernels_lowbit_asym": out}
+
+
+EXTRA_ENTRIES = [export_entries, qlinear_entries, lowbit_asym_entries]
 
 
 if __name__ == "__main__":

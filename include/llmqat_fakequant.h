@@ -230,6 +230,18 @@ int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_
                int dtype, void* stream);
 
 /*
+ * The same branches with the per-row scale reduced INSIDE the kernel (per-row `abs().mean(dim=1)`, :205-209 / :219-224;
+ * weight_layerwise is not served): one launch, read w + write out, instead of ATen's abs + mean + fq_w12_fwd.
+ * OPT-IN: the mean is a floating-point sum and this kernel's summation order is its own, not ATen's -- for bf16 / fp16
+ * tensors the scale (rounded to the tensor dtype) differs from ATen's for about one row in a few thousand, for fp32 in the
+ * last bit routinely; fq_w12_fwd with ATen's own reduction stays the bit-exact default.
+ *   scale_out  optional [rows] values of `dtype`: the scaling factor used (mean|w|, or 2*mean|w| for 2 bits)
+ *   sem        FQ_SEM_CPU_EAGER: mean = sum / n;  FQ_SEM_DEVICE_EAGER: mean = sum * (1/n), as ATen's GPU kernel
+ * FQ_ERR_UNSUPPORTED unless rows are 16-byte aligned, cols a multiple of a 16-byte vector and <= 8192 vectors.
+ */
+int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int dtype, int sem, void* stream);
+
+/*
  * ---- the integer side of the fake-quant forward ---------------------------------------------------------
  *
  * The reference never materialises integers: `output = torch.round(input * s).div(s + 1e-6)` (models/utils_quant.py:72)

@@ -20,7 +20,7 @@ EXPORTS = (
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
     "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
-    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_qlinear_fwd", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi",
+    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_qlinear_fwd", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi", "fq_w12_fwd_rows",
 )
 MAX_TENSORS = 4  # tensors per multi-tensor launch
 
@@ -94,6 +94,8 @@ def _bind(L):
     L.fq_sym_row_scales.restype = i32
     L.fq_qlinear_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp]
     L.fq_qlinear_fwd.restype = i32
+    L.fq_w12_fwd_rows.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    L.fq_w12_fwd_rows.restype = i32
     L.fq_sym_fwd_multi.argtypes = [i32, ctypes.POINTER(FwdTensor), i64, i32, i32, i32, f32, f32, vp]
     L.fq_sym_fwd_multi.restype = i32
     L.fq_ste_bwd_mask_multi.argtypes = [i32, ctypes.POINTER(BwdTensor), i64, f32, f32, i32, i32, vp]

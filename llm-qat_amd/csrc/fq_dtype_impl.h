@@ -345,6 +345,38 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     return launch_result();
 }
 
+template <int DT>
+int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    clear_stale_error();
+    const int64_t nvec = cols / EPV;
+    if (!(aligned16(w) && aligned16(out) && cols % EPV == 0 && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "fused 1-/2-bit branch: rows must be 16-byte aligned and fit the register kernels");
+    if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);
+    const bool dev = sem == FQ_SEM_DEVICE_EAGER;
+#define R(TPR, V)                                                                                                                         \
+    case V:                                                                                                                               \
+        if (w_bits == 1) {                                                                                                                \
+            if (dev) FQ_LAUNCH((w12_row_kernel<DT, 1, TPR, V, true>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);  \
+            else FQ_LAUNCH((w12_row_kernel<DT, 1, TPR, V, false>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);    \
+        } else {                                                                                                                          \
+            if (dev) FQ_LAUNCH((w12_row_kernel<DT, 2, TPR, V, true>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);  \
+            else FQ_LAUNCH((w12_row_kernel<DT, 2, TPR, V, false>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);    \
+        }                                                                                                                                 \
+        break;
+    if (nvec <= 256) {
+        switch ((int)((nvec + 63) / 64)) { R(64, 1) R(64, 2) R(64, 3) R(64, 4) }
+    } else if (nvec <= 1024) {
+        switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) R(256, 4) }
+    } else if (nvec <= 4096) {
+        switch ((int)((nvec + 511) / 512)) { R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+    } else {
+        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+    }
+#undef R
+    return launch_result();
+}
+
 #define FQ_INSTANTIATE(DT)                                                                                      \
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
     template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
@@ -352,6 +384,7 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
     template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
     template int launch_ste_mask_wide<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
-    template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
+    template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);     \
+    template int launch_w12_rows<DT>(const void*, void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 
 }  // namespace fq

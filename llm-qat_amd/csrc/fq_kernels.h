@@ -836,6 +836,77 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
     }
 }
 
+// 1-/2-bit weight branch in ONE pass (opt-in): the per-row mean|w| scale is reduced here, in fp32, in this kernel's own
+// summation order (thread-sequential over its 16-byte vectors, butterfly across the wave, then across waves), instead of
+// by ATen's `abs().mean(dim=1)` -- one launch and 4 B/elem (bf16) instead of three launches and ~10 B/elem.  A
+// floating-point sum depends on its order: for 16-bit tensors the fp32 sum is rounded to 8 / 11 significant bits, so two
+// orders disagree only when the sum lies within ~2^-20 of a rounding boundary (about one row in a few thousand); for fp32
+// tensors the last bit differs routinely.  That is why this path is opt-in and ATen's reduction stays the default.
+template <int DT, int WBITS, int TPR, int VPT, bool DEVSEM>
+__global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const void* __restrict__ w, void* __restrict__ out, void* __restrict__ scale_out,
+                                                                        int64_t rows, int64_t cols, float cv) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    constexpr int NW = TPR / 64;
+    __shared__ float red[NW > 1 ? NW : 1];
+    int64_t row;
+    int t;
+    if constexpr (TPR == 64) {
+        row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        t = threadIdx.x & 63;
+        if (row >= rows) return;
+    } else {
+        row = blockIdx.x;
+        t = threadIdx.x;
+    }
+    const int nvec = (int)(cols / EPV);
+    const uint4* __restrict__ xr = (const uint4*)((const char*)w + row * cols * T::ESIZE);
+    uint4* __restrict__ yr = (uint4*)((char*)out + row * cols * T::ESIZE);
+    uint4 r[VPT];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = t + i * TPR;
+        r[i] = xr[v < nvec ? v : nvec - 1];
+        const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float f[T::EPD];
+            T::unpack(wd[d], f);
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) acc += (v < nvec) ? __builtin_fabsf(f[k]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if constexpr (NW > 1) {
+        if ((t & 63) == 0) red[t >> 6] = acc;
+        __syncthreads();
+        acc = red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) acc += red[i];
+    }
+    // torch.mean: CPU divides the sum by n, the GPU kernel multiplies by a float 1/n
+    float sc = T::rb(DEVSEM ? acc * (1.0f / (float)cols) : acc / (float)cols);
+    if constexpr (WBITS == 2) sc = T::rb(2.0f * sc);
+    if (t == 0 && scale_out) T::store1(scale_out, row, sc);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = t + i * TPR;
+        const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float f[T::EPD];
+            T::unpack(wd[d], f);
+#pragma unroll
+            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv);
+            o[d] = T::pack(f);
+        }
+        if (v < nvec) yr[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
 // clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
 // every wave covers exactly one mask group per slot.

@@ -153,6 +153,8 @@ FQ_HIDDEN int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_
 template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);
+template <int DT>
+FQ_HIDDEN int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st);
 // words (uint64) of STE mask per row; 0 if the shape is not served by the mask path
 inline int64_t mask_row_words(int64_t cols, int esize) {
     const int epv = 16 / esize;

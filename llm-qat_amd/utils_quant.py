@@ -182,6 +182,35 @@ class _LowBitWeight(torch.autograd.Function):
         return grad_output, None, None
 
 
+class _LowBitWeightFused(torch.autograd.Function):
+    """the same value from the one-launch kernel (its own row mean); identity gradient"""
+
+    @staticmethod
+    def forward(ctx, w, w_bits):
+        res = ops.low_bit_weight_fused(w, w_bits)
+        if res is None:
+            raise _NotServed()
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None
+
+
+class _NotServed(Exception):
+    pass
+
+
+# 1-/2-bit weights in one launch with the row mean reduced in-kernel: OPT-IN (LLMQAT_AMD_W12_FUSED=1 / fuse_low_bit_mean),
+# because a float sum's order is the kernel's own -- the default keeps ATen's reduction and is bit-exact to the reference.
+_W12_FUSED = os.environ.get("LLMQAT_AMD_W12_FUSED", "0") == "1"
+
+
+def fuse_low_bit_mean(flag=True):
+    global _W12_FUSED
+    _W12_FUSED = bool(flag)
+
+
 _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every call (:198, :245)
 
 # ---------------------------------------------------------------------------------------------
@@ -440,6 +469,11 @@ class QuantizeLinear(nn.Linear):
         gradient (the reference's detach trick).  The mean stays ATen's reduction (a sum is order dependent;
         this keeps the scale bit-identical to the reference's); the ~10 elementwise kernels after it are one
         HIP kernel."""
+        if _W12_FUSED and not self.weight_layerwise and w.is_cuda and w.is_contiguous():
+            try:
+                return _LowBitWeightFused.apply(w, self.w_bits)
+            except _NotServed:
+                pass
         with torch.no_grad():
             absmean = w.abs().mean() if self.weight_layerwise else w.abs().mean(dim=1, keepdim=True)
             sc = absmean if self.w_bits == 1 else 2 * absmean

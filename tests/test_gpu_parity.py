@@ -502,6 +502,20 @@ def test_sym_under_autocast_vs_live_aten(ops, dtype):
     rng = np.random.default_rng(31)
     clip = torch.tensor([-2.0, 2.0])
     prev = llm_qat_amd.get_backward_mode()
+    # GUARD.  The autocast arithmetic is pinned by live ATen on this GPU, not by reference fixtures
+    # (none can exist: CPU autocast does not promote `reciprocal`).  Which kernel the drop-in selects rests on ONE fact
+    # about this torch build -- `reciprocal` is on CUDA autocast's fp32 list, so `int / Tensor` (utils_quant.py:71) comes
+    # back in fp32 while the `max + 1e-6` in front of it stays in the tensor dtype.  If a torch upgrade changes the
+    # autocast lists this fails loudly instead of ops.autocast_active() silently picking the wrong arithmetic.
+    with torch.autocast("cuda", dtype=TD[dtype]):
+        probe = torch.rand(4, 64, device="cuda").to(TD[dtype]) + 0.5
+        top = torch.max(torch.abs(probe), dim=-1, keepdim=True)[0].expand_as(probe)
+        t1 = top + 1e-6
+        s = 127 / t1
+        assert top.dtype == TD[dtype] and t1.dtype == TD[dtype], "abs / max / add are no longer dtype-preserving under autocast"
+        assert s.dtype == torch.float32, "`int / Tensor` no longer autocasts to fp32: the autocast op lists of this torch build changed"
+        assert (probe * s).dtype == torch.float32 and torch.round(probe * s).div(s + 1e-6).dtype == torch.float32
+        assert torch.reciprocal(t1).dtype == torch.float32
     try:
         for shape in [(16, 256), (8, 4096), (3, 11008), (5, 33), (2, 3, 64), (4, 4104), (2, 20000)]:
             for style, bits in (("act", 8), ("weight", 4), ("mixed", 8), ("mixed", 16)):

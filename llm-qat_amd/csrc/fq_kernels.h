@@ -815,6 +815,8 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
         const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (v >= nvec) return;
         const float sc = T::load1(scale, scale_per_row ? v / nvec_row : 0);
+        const float rsc = 1.0f / sc;
+        const bool mk = div_exact_ok(sc);
         const uint4 r = ((const uint4*)w)[v];
         const uint32_t in[4] = {r.x, r.y, r.z, r.w};
         uint32_t o[4];
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
             float f[T::EPD];
             T::unpack(in[d], f);
 #pragma unroll
-            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv);
+            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv, rsc, mk);
             o[d] = T::pack(f);
         }
         ((uint4*)out)[v] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
         const int64_t n = rows * cols, stride = (int64_t)gridDim.x * 256;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
             const float sc = T::load1(scale, scale_per_row ? i / cols : 0);
-            T::store1(out, i, w12_elem<DT, WBITS>(T::load1(w, i), sc, cv));
+            T::store1(out, i, w12_elem<DT, WBITS>(T::load1(w, i), sc, cv, 1.0f / sc, div_exact_ok(sc)));
         }
     }
 }
@@ -890,6 +892,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const vo
     float sc = T::rb(DEVSEM ? acc * (1.0f / (float)cols) : acc / (float)cols);
     if constexpr (WBITS == 2) sc = T::rb(2.0f * sc);
     if (t == 0 && scale_out) T::store1(scale_out, row, sc);
+    const float rsc = 1.0f / sc;
+    const bool mk = div_exact_ok(sc);
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int v = t + i * TPR;
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const vo
             float f[T::EPD];
             T::unpack(wd[d], f);
 #pragma unroll
-            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv);
+            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv, rsc, mk);
             o[d] = T::pack(f);
         }
         if (v < nvec) yr[v] = make_uint4(o[0], o[1], o[2], o[3]);

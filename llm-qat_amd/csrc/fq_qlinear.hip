@@ -13,8 +13,8 @@
 // 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 with W as the A operand and x as the B operand (so the accumulator holds, per
 // lane, 4 consecutive OUTPUT columns of one token row: 8-byte stores).  LDS: two stages x (16 KiB W + 32 KiB x), rows of
 // 128 B with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 -- conflict-free for ds_read_b128's 16-lane groups
-// and for the row-contiguous ds_write_b128.  One barrier per K-step; the global loads of tile t+2 are in flight while tile
-// t+1 is quantized into the other stage and tile t is multiplied.
+// and for the row-contiguous ds_write_b128.  One barrier per K-step; two register sets keep the global loads of tiles t+1
+// and t+2 in flight while tile t is multiplied, then tile t+1 is quantized into the other LDS stage.
 // Grid: one block per tile, tile index remapped so that the blocks of one XCD (blockIdx % 8) cover a compact
 // 8 x 4 patch of tiles (they share W / x panels in that XCD's L2).  Speed only; any placement is correct.
 #include "../../include/llmqat_fakequant.h"
@@ -127,14 +127,18 @@ __global__ __launch_bounds__(QL_THREADS, 2) void qlinear_kernel(QLArgs a) {
             xq[i].rinv = 1.0f / xq[i].t2;
         }
     }
-    uint4 rw[2], rx[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rw[i] = *(const uint4*)(wp[i] + kt * QL_BK);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rx[i] = *(const uint4*)(xp[i] + kt * QL_BK);
+    struct Regs {
+        uint4 w[2], x[4];
     };
-    auto stage = [&](int buf, int kt) {
+    auto gload = [&](Regs& r, int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r.w[i] = *(const uint4*)(wp[i] + kt * QL_BK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.x[i] = *(const uint4*)(xp[i] + kt * QL_BK);
+    };
+    auto stage = [&](int buf, int kt, const Regs& r) {
+        const uint4* rw = r.w;
+        const uint4* rx = r.x;
         char* sw = smem + buf * QL_STAGE;
         char* sx = sw + QL_W_BYTES;
 #pragma unroll
@@ -192,20 +196,31 @@ __global__ __launch_bounds__(QL_THREADS, 2) void qlinear_kernel(QLArgs a) {
     };
 
     const int nk = K / QL_BK;
-    gload(0);
-    stage(0, 0);
+    Regs ra, rb;   // two register sets: the global loads of tiles t+1 AND t+2 are in flight while tile t is multiplied
+    gload(ra, 0);
+    stage(0, 0, ra);
     __syncthreads();
-    if (nk > 1) gload(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        compute(ABL == 2 ? 0 : cur);
+    if (nk > 1) gload(ra, 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: LDS stage 0 holds tile kt, `ra` tile kt+1; tile kt+2 starts its flight into `rb`
         if constexpr (ABL != 2) {
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            if (kt + 2 < nk) gload(rb, kt + 2);
+        }
+        compute(0);
+        if constexpr (ABL != 2) {
+            if (kt + 1 < nk) stage(1, kt + 1, ra);
         }
         __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: stage 1 holds tile kt+1, `rb` tile kt+2; tile kt+3 starts its flight into `ra`
         if constexpr (ABL != 2) {
-            if (kt + 2 < nk) gload(kt + 2);
+            if (kt + 3 < nk) gload(ra, kt + 3);
         }
+        compute(ABL == 2 ? 0 : 1);
+        if constexpr (ABL != 2) {
+            if (kt + 2 < nk) stage(0, kt + 2, rb);
+        }
+        __syncthreads();
     }
 
     // ---- epilogue: acc[i][j][reg]: out column n = n0 + wn*64 + i*32 + 8*(reg>>2) + 4*fh + (reg&3), token m = m0 + wm*64 + j*32 + fr

@@ -591,6 +591,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip per-kernel / eager measurements")
+    ap.add_argument("--core-extras", action="store_true",
+                    help="per-kernel entries of the step's own kernels only (no model shapes / export / fused GEMM / eager / CPU): what "
+                         "tools/profile_bench.sh runs under rocprofv3, so that every fq:: kernel in the trace has ONE launch shape per role")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test: the step is a short sleep, no GPU is touched, the process group is gloo. "
                          "The JSON line says data='stub'; it is never a measurement.")
@@ -810,13 +813,14 @@ def main(argv=None):
                                  "us_per_launch": round(cmean * 1e3, 2), "gbs": round(nb * FWD_BYTES_PER_ELEM / (cmean * 1e-3) / 1e9, 1),
                                  "us_p10_p50_p90": [round(v * 1e3, 2) for v in cpct]}
         # the launches of one LLaMA-7B layer at their real shapes
-        out["kernels_model_shapes"] = ModelShapes(wl).entries(it)
-        for hook in EXTRA_ENTRIES:   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
+        if not args.core_extras:
+            out["kernels_model_shapes"] = ModelShapes(wl).entries(it)
+        for hook in ([] if args.core_extras else EXTRA_ENTRIES):   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
             try:
                 out.update(hook(wl, it))
             except Exception as e:  # noqa: BLE001  -- an extra entry must never lose the headline line
                 out.setdefault("extras_failed", []).append(f"{getattr(hook, '__name__', hook)}: {e!r}")
-        if world == 1:
+        if world == 1 and not args.core_extras:
             out["gpu_eager"] = gpu_eager(wl)
             out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)
             if not args.no_cpu_baseline:

@@ -57,7 +57,7 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline  (MI355X, gfx950)"])
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras  (MI355X, gfx950)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
             w.writerow([short(r["Name"])[:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
@@ -156,6 +156,10 @@ def main():
     if "sym_fwd_w4" in traffic:
         traffic["sym_fwd_w4_plain"] = traffic["sym_fwd_w4"]
     json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    import time
+    traffic["_source"] = (f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, FETCH_SIZE x2 per the gfx950 "
+                          f"rule) of `bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras`, collected {time.strftime('%Y-%m-%d')} on one MI355X; "
+                          "NOT measured in the run that prints this line")
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
     for k, v in dur.items():

@@ -118,3 +118,92 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
             everything.append(sc)
             for wb in (1, 2):
                 ok(L.fq_w12_fwd(x.ptr, sc.ptr, y.ptr, rows, cols, wb, 1, code, st), "w12_fwd")
+
+
+@pytest.mark.parametrize("dtype,code,es", [(torch.bfloat16, 1, 2), (torch.float32, 0, 4), (torch.float16, 2, 2)])
+def test_round2_entry_points_stay_inside_their_buffers(dtype, code, es):
+    """the round-2 entry points under the same canary regime: packed export (every container, register and generic paths),
+    the scale pre-pass with bounds + mask, the one-launch W1/W2 kernel, and 3- / 4-tensor launches (forward + backward)"""
+    import ctypes
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for rows, cols in SHAPES:
+        n = rows * cols
+        for off in (0, 2 if es == 2 else 4):
+            x = Guarded(n * es, off)
+            x.payload().view(dtype).copy_((torch.randn(n, generator=g, device="cuda") * 1.5).to(dtype))
+            y = Guarded(n * es, off)
+            scales, over, bounds, sc16 = Guarded(rows * 8), Guarded(rows * 4), Guarded(rows * 8), Guarded(rows * es)
+            mb = L.fq_ste_mask_bytes(rows, cols, code)
+            mask = Guarded(max(mb, 8))
+            everything = [x, y, scales, over, bounds, sc16, mask]
+            tag = f"{dtype} [{rows},{cols}] off={off}"
+
+            def ok(rc, what, allow=()):
+                assert rc == 0 or rc in allow, f"{tag} {what}: rc={rc} {L.fq_last_error()}"
+                torch.cuda.synchronize()
+                for b in everything:
+                    assert b.intact(), f"{tag} {what}: canary overwritten"
+
+            for cont in (_lib.BINS_INT4, _lib.BINS_INT8, _lib.BINS_INT16):
+                nb = L.fq_export_bins_bytes(rows, cols, cont)
+                for boff in (0, 1):                     # byte-aligned bins buffers too: generic path
+                    bins = Guarded(nb, boff)
+                    everything.append(bins)
+                    for bits in (4, 8):
+                        ok(L.fq_sym_export(x.ptr, bins.ptr, scales.ptr, over.ptr, rows, cols, bits, cont, code, 0, 0, st), "sym_export")
+                        ok(L.fq_asym_export(x.ptr, bins.ptr, scales.ptr, over.ptr, rows, cols, bits, cont, code, 0, st), "asym_export")
+                    if es == 2:
+                        ok(L.fq_sym_export(x.ptr, bins.ptr, scales.ptr, None, rows, cols, 8, cont, code, 0, 1, st), "sym_export autocast")
+                    everything.pop()
+                    assert bins.intact()
+            ok(L.fq_sym_row_scales(x.ptr, scales.ptr, rows, cols, 8, code, 0, 0, -2.0, 2.0, None, None, 0, st), "row_scales")
+            if mb:
+                ok(L.fq_sym_row_scales(x.ptr, scales.ptr, rows, cols, 8, code, 0, 0, -2.0, 2.0, bounds.ptr, mask.ptr, mb, st), "row_scales + mask", allow=(-8,))
+            for wb in (1, 2):
+                ok(L.fq_w12_fwd_rows(x.ptr, y.ptr, sc16.ptr, rows, cols, wb, code, 0, st), "w12_fwd_rows", allow=(-8,))
+            if mb and off == 0:
+                for nt in (3, 4):
+                    rws = [rows, max(1, rows // 2), rows + 1, 2][:nt]
+                    fw = (_lib.FwdTensor * nt)()
+                    bw = (_lib.BwdTensor * nt)()
+                    keep = []
+                    for i, r in enumerate(rws):
+                        xi, yi, gi, gxi, bi = Guarded(r * cols * es), Guarded(r * cols * es), Guarded(r * cols * es), Guarded(r * cols * es), Guarded(r * 8)
+                        mbi = L.fq_ste_mask_bytes(r, cols, code)
+                        mi = Guarded(mbi)
+                        xi.payload().view(dtype).copy_((torch.randn(r * cols, generator=g, device="cuda") * 1.5).to(dtype))
+                        gi.payload().view(dtype).copy_(torch.randn(r * cols, generator=g, device="cuda").to(dtype))
+                        keep += [xi, yi, gi, gxi, bi, mi]
+                        fw[i] = _lib.FwdTensor(xi.ptr, yi.ptr, r, 4 + i, bi.ptr, mi.ptr, mbi)
+                        bw[i] = _lib.BwdTensor(gi.ptr, gxi.ptr, r, bi.ptr, mi.ptr)
+                    everything += keep
+                    rc = L.fq_sym_fwd_multi(nt, fw, cols, code, 0, 0, -2.0, 2.0, st)
+                    ok(rc, f"sym_fwd_multi n={nt}", allow=(-8,))
+                    if rc == 0:
+                        ok(L.fq_ste_bwd_mask_multi(nt, bw, cols, -2.0, 2.0, code, 0, st), f"ste_bwd_mask_multi n={nt}", allow=(-8,))
+                    del everything[-len(keep):]
+
+
+def test_qlinear_stays_inside_its_buffers():
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for m, n, k in [(1, 4, 64), (300, 388, 192), (257, 132, 128), (512, 256, 64)]:
+        x, w, out = Guarded(m * k * 2), Guarded(n * k * 2), Guarded(m * n * 2)
+        xs, ws, dx, dw = Guarded(m * 8), Guarded(n * 8), Guarded(m * k * 2), Guarded(n * k * 2)
+        x.payload().view(torch.bfloat16).copy_(torch.randn(m * k, generator=g, device="cuda").bfloat16())
+        w.payload().view(torch.bfloat16).copy_((torch.randn(n * k, generator=g, device="cuda") * 0.02).bfloat16())
+        every = [x, w, out, xs, ws, dx, dw]
+        assert L.fq_sym_row_scales(x.ptr, xs.ptr, m, k, 8, 1, 0, 0, -2.0, 2.0, None, None, 0, st) == 0
+        assert L.fq_sym_row_scales(w.ptr, ws.ptr, n, k, 4, 1, 0, 0, -2.0, 2.0, None, None, 0, st) == 0
+        for qa, qw, ac, dump, abl in [(1, 1, 0, 1, 0), (0, 1, 0, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 0, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1), (1, 1, 0, 0, 2)]:
+            rc = L.fq_qlinear_fwd(x.ptr, xs.ptr if qa else None, w.ptr, ws.ptr if qw else None, out.ptr, m, k, n, 1, ac,
+                                  dx.ptr if dump else None, dw.ptr if dump else None, abl, st)
+            assert rc == 0, L.fq_last_error()
+            torch.cuda.synchronize()
+            for b in every:
+                assert b.intact(), f"qlinear [{m},{k}]x[{n},{k}] qa={qa} qw={qw} ac={ac} dump={dump} abl={abl}: canary overwritten"

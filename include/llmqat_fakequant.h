@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FQ_ABI_VERSION 1
+#define FQ_ABI_VERSION 2 /* 2: + multi-tensor launches, export, row scales, fq_qlinear_fwd, fq_w12_fwd_rows */
 
 /* element types */
 #define FQ_DTYPE_F32 0

@@ -132,8 +132,10 @@ class Workload:
         if rc:
             self._lib.check(rc, "fq_sym_fwd_train")
 
-    def bwd(self, s, leg):
+    def bwd(self, s, leg, inplace=False):
         g, gx, b, m = (s["gw"], s["gxw"], s["bw"], s["mw"]) if leg == "w" else (s["ga"], s["gxa"], s["ba"], s["ma"])
+        if inplace:
+            gx = g
         rc = self.L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), self.rows, self.cols, -2.0, 2.0, b.data_ptr(), m.data_ptr(),
                                     self.mask_bytes, self._lib.DTYPE_BF16, self.stream)
         if rc:
@@ -177,8 +179,11 @@ class Workload:
         if rc:
             self._lib.check(rc, "fq_sym_fwd_pair")
 
-    def bwd_pair(self, s):
-        rc = self.L.fq_ste_bwd_mask_pair(s["gw"].data_ptr(), s["gxw"].data_ptr(), self.rows, s["bw"].data_ptr(), s["mw"].data_ptr(),
+    def bwd_pair(self, s, inplace_w=True):
+        # the product's default (utils_quant.py, point 6): the WEIGHT's gradient is masked where it stands (gx == g) -- its rows
+        # cannot clip, so the kernel touches none of it; the activation's gradient is written to a fresh tensor as always
+        gxw = s["gw"] if inplace_w else s["gxw"]
+        rc = self.L.fq_ste_bwd_mask_pair(s["gw"].data_ptr(), gxw.data_ptr(), self.rows, s["bw"].data_ptr(), s["mw"].data_ptr(),
                                          s["ga"].data_ptr(), s["gxa"].data_ptr(), self.rows, s["ba"].data_ptr(), s["ma"].data_ptr(),
                                          self.cols, -2.0, 2.0, self._lib.DTYPE_BF16, self.stream)
         if rc:
@@ -198,7 +203,7 @@ class Workload:
         self.fwd(sf, "w")
         self.fwd(sf, "a")
         self.bwd(sb, "a")
-        self.bwd(sb, "w")
+        self.bwd(sb, "w", inplace=True)
 
     def prime_bounds(self):
         for s in self.sets:
@@ -304,7 +309,8 @@ class ModelShapes:
                                        cols, code, 0, autocast, -2.0, 2.0, st), "fq_sym_fwd_pair")
         return fn, sets
 
-    def pair_bwd(self, rows0, style0, rows1, style1, cols, wide=False):
+    def pair_bwd(self, rows0, style0, rows1, style1, cols, wide=False, inplace0=False):
+        """inplace0: tensor 0 is a weight whose gradient the product masks where it stands (gx == g)"""
         L, code, st = self.L, self._lib.DTYPE_BF16, self.wl.stream
         s0 = self.sets_for(rows0, cols, style0, wide)
         s1 = self.sets_for(rows1, cols, style1 + "2", wide)
@@ -314,7 +320,7 @@ class ModelShapes:
 
         def fn(s):
             a, b = s["a"], s["b"]
-            self.chk(f(a[gk].data_ptr(), a["gx"].data_ptr(), rows0, a["b"].data_ptr(), a["m"].data_ptr(),
+            self.chk(f(a[gk].data_ptr(), (a[gk] if inplace0 else a["gx"]).data_ptr(), rows0, a["b"].data_ptr(), a["m"].data_ptr(),
                        b[gk].data_ptr(), b["gx"].data_ptr(), rows1, b["b"].data_ptr(), b["m"].data_ptr(), cols, -2.0, 2.0, code, st), "pair_bwd")
         return fn, sets
 
@@ -346,7 +352,9 @@ class ModelShapes:
         add("q_proj pair fwd: W4 [4096,4096] + A8 [2048,4096]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H)
         add("W4 [11008,4096] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True)
         # backward launches (their forwards above have filled bounds + masks of the same buffers)
-        add("down_proj pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I)
+        add("down_proj pair bwd (weight gradient in place: product default)", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I, inplace0=True),
+            T * I, False, T * I)
+        add("down_proj pair bwd, both gradients to fresh tensors", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I)
         add("A8 [2048,4096] bwd", "utils_quant.py:77-87", self.single_bwd(T, H, "a"), T * H, False, T * H)
         add("quantize_kv pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(T, "a", T, "a", H), 2 * T * H, False, 2 * T * H)
         add("quantize_kv pair bwd under autocast: fp32 grads in, bf16 out", "utils_quant.py:77-87 x2 + the engine's cast",
@@ -724,7 +732,9 @@ def main(argv=None):
     clip_frac = wl.clippable_fraction()
     mask_bytes_a = int(wl.n * clip_frac) // 8          # 1 bit/element for the A8 tensor's clippable rows; the W4 tensor has none
     algo_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_BYTES_PER_ELEM)
-    moved_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_MASK_BYTES_PER_ELEM) + 2 * mask_bytes_a
+    # bytes the step's two launches move: forward 4 B/elem (+ mask bits); backward 4 B/elem for the A8 tensor (+ mask bits) and
+    # NOTHING for the W4 tensor, whose gradient is handed on by reference (in place, no row can clip)
+    moved_bytes_step = elems_step * FWD_BYTES_PER_ELEM + wl.n * BWD_MASK_BYTES_PER_ELEM + 2 * mask_bytes_a
 
     out = {
         "metric": baseline_metric_name(),
@@ -735,7 +745,9 @@ def main(argv=None):
                                "[4096,11008], bf16, clip [-2,2] (LLaMA-7B W4-A8 down_proj shapes, configs[1])",
                    "elements_per_step": elems_step, "buffer_sets": wl.nsets, "parallelism": "replicas" if world > 1 else "1gpu",
                    "semantics": "cpu_eager",
-                   "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x)",
+                   "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x); the weight's gradient "
+                               "is masked in place (gx == g: rows that cannot clip -- all of a weight's -- are not touched), the "
+                               "activation's is written to a fresh tensor",
                    "launches_per_step": "2 (weight + input of a QuantizeLinear share one forward and one backward launch)"},
         "hbm_gbs_moved": round(moved_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
         "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
@@ -759,14 +771,14 @@ def main(argv=None):
         }
         pk = {
             "sym_fwd_pair_w4a8": (lambda s: wl.fwd_pair(s), 2 * nb * FWD_BYTES_PER_ELEM, fwd_w + fwd_a),
-            "ste_bwd_pair_w4a8": (lambda s: wl.bwd_pair(s), 2 * nb * BWD_BYTES_PER_ELEM, bwd_w + bwd_a),
+            "ste_bwd_pair_w4a8 (weight gradient in place)": (lambda s: wl.bwd_pair(s), 2 * nb * BWD_BYTES_PER_ELEM, bwd_a),
         }
 
         def pair_traffic(k):
             if k in traffic:
                 return traffic[k]
-            parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8"), "ste_bwd_pair_w4a8": ("ste_bwd_w4", "ste_bwd_a8")}[k]
-            return sum(traffic[p] for p in parts) if all(p in traffic for p in parts) else None
+            parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8")}.get(k)
+            return sum(traffic[p] for p in parts) if parts and all(p in traffic for p in parts) else None
 
         out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it), pair_traffic(k), moved_bytes=mv, traffic_source=tsrc)
                                for k, (fn, b, mv) in pk.items()]
@@ -778,6 +790,14 @@ def main(argv=None):
             "ste_bwd_a8_xread": (lambda s: wl.bwd_xread(s, "a"), nb * BWD_BYTES_PER_ELEM),
         }
         out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in alt.items()]
+        # the backward as a copy (gx != g for the weight too: what round 1 measured) and the weight's in-place launch alone
+        out["kernels_step_out_of_place"] = [roofline_entry("ste_bwd_pair_w4a8 (both gradients to fresh tensors)", 2 * nb * BWD_BYTES_PER_ELEM,
+                                                           wl.time_kernel(lambda s: wl.bwd_pair(s, inplace_w=False), it), traffic.get("ste_bwd_pair_w4a8"),
+                                                           moved_bytes=bwd_w + bwd_a, traffic_source=tsrc)]
+        tw = wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it)
+        out["ste_bwd_w4_in_place"] = {"us_per_launch": round(tw[0] * 1e3, 2), "us_p10_p50_p90": [round(v * 1e3, 2) for v in tw[1]],
+                                      "what": "fq_ste_bwd_mask with gx == g on the W4 tensor: every row's bounds prove nothing clips, the kernel exits "
+                                              "before any vector memory operation (launch + 8 B per row)"}
         ac = {
             "sym_fwd_w4_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "w", False), nb * FWD_BYTES_PER_ELEM),
             "sym_fwd_a8_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "a", False), nb * FWD_BYTES_PER_ELEM),
@@ -804,7 +824,7 @@ def main(argv=None):
                                 "frac_algorithmic_note": "10 B/elem reference-dataflow equivalent (SURVEY §8d), not a byte rate",
                                 "what": "both launches of one step: bytes moved / sum of launch times"}
         out["unpaired_step"] = {"ms_per_step": round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
-                                "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2)"}
+                                "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2; weight gradient in place)"}
         out["autograd_path"] = autograd_path(wl)
         # a live yardstick for "how fast can this device move the same bytes": ATen's device-to-device copy of the W tensor
         # (read 90.2 MB + write 90.2 MB = one single-tensor forward's algorithmic bytes), timed like the kernels above

@@ -132,6 +132,10 @@ int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
  *                    Returns FQ_ERR_UNSUPPORTED if x/y are not 16-byte aligned.
  * fq_ste_bwd_mask    SymQuantizer.backward / AsymQuantizer.backward (utils_quant.py:77-87, :152-162) from
  *                    (row_bounds, mask) of the matching forward; lo/hi must be the same values.
+ *                    IN PLACE: gx may be the same pointer as g (also per tensor in fq_ste_bwd_mask_pair / _multi).  The
+ *                    gradient is then masked where it stands, and a row whose bounds prove that nothing is clipped is not
+ *                    touched at all: for a weight (whose rows practically never reach the clip) the STE backward moves no
+ *                    bytes -- the reference's `grad_output.clone()` (:84) exists only to be mutated by :85-86.
  */
 size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype);
 int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,

@@ -959,7 +959,7 @@ struct SteMore {  // optional further tensors of a mask-backward launch (same dt
 };
 
 template <int DT, int VPT, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nvec_row,
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* g, void* gx, int64_t nvec_row,  // gx may alias g (in place)
                                                                int64_t chunks, int cv, const float* __restrict__ bounds,
                                                                const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
                                                                float hi, SteMore more) {
@@ -980,14 +980,17 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* __res
         }
         row -= rbase;
     }
+    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+    const bool safe = (ub < hi) && (lb > lo);
+    // In place (gx == g, e.g. a weight's gradient handed on by reference): a row that cannot clip needs nothing at all --
+    // the identity part of the STE costs no traffic.  Block-uniform exit before any vector memory operation.
+    if (safe && gx == (const void*)g) return;
     const int64_t vs = (blockIdx.x % chunks) * cv;
     const int64_t off = row * nvec_row + vs;
     const uint4* gr = (const uint4*)g + off;
     uint4* or_ = (uint4*)gx + off;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
-    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
-    const bool safe = (ub < hi) && (lb > lo);
     const int t = threadIdx.x;
     uint4 rg[VPT];
 #pragma unroll

@@ -182,12 +182,14 @@ def train_forward(kind, x, num_bits, layerwise, lo, hi):
     return y, side, rows, cols
 
 
-def train_backward(grad_output, side, rows, cols, lo, hi):
+def train_backward(grad_output, side, rows, cols, lo, hi, inplace=False):
+    """inplace: mask the gradient where it stands and return it (fq_ste_bwd_mask with gx == g): rows that cannot clip are
+    not touched, so a weight's gradient costs a launch and no traffic.  Only for callers that own grad_output exclusively."""
     code = _DTYPES.get(grad_output.dtype)
     if code is None or grad_output.device.type != "cuda":
         _prep(grad_output, "ste_backward")
     g = _aligned(grad_output)
-    gx = torch.empty_like(g)
+    gx = g if inplace else torch.empty_like(g)
     sp = side.data_ptr()
     dev = g.device.index
     L = _lib.lib()
@@ -312,20 +314,22 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     return wq, xq, side_w, side_x, rows_w, rows_x, cols
 
 
-def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi):
-    """STE backward of both operands in one launch; either gradient may be None (then only the other is computed)."""
+def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, inplace_w=False):
+    """STE backward of both operands in one launch; either gradient may be None (then only the other is computed).
+    inplace_w: the first tensor's gradient (a weight's) is masked where it stands and returned itself (see train_backward)."""
     if gw is None or gx is None:
-        g, side, rows = (gw, side_w, rows_w) if gx is None else (gx, side_x, rows_x)
-        return (train_backward(g, side, rows, cols, lo, hi), None) if gx is None else (None, train_backward(g, side, rows, cols, lo, hi))
+        if gx is None:
+            return train_backward(gw, side_w, rows_w, cols, lo, hi, inplace=inplace_w), None
+        return None, train_backward(gx, side_x, rows_x, cols, lo, hi)
     code = _DTYPES.get(gw.dtype)
     gw, gx = _aligned(gw), _aligned(gx)
-    ow, ox = torch.empty_like(gw), torch.empty_like(gx)
+    ow, ox = (gw if inplace_w else torch.empty_like(gw)), torch.empty_like(gx)
     pw, px = side_w.data_ptr(), side_x.data_ptr()
     with _DeviceOf(gw):
         rc = _lib.lib().fq_ste_bwd_mask_pair(gw.data_ptr(), ow.data_ptr(), rows_w, pw, pw + rows_w * 8,
                                              gx.data_ptr(), ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, float(lo), float(hi), code, _stream(gw))
     if rc == _lib.ERR_UNSUPPORTED:
-        return train_backward(gw, side_w, rows_w, cols, lo, hi), train_backward(gx, side_x, rows_x, cols, lo, hi)
+        return train_backward(gw, side_w, rows_w, cols, lo, hi, inplace=inplace_w), train_backward(gx, side_x, rows_x, cols, lo, hi)
     _lib.check(rc, "quantize_linear_pair_backward")
     return ow, ox
 
@@ -388,21 +392,23 @@ def multi_forward(tensors, bits, need, lo, hi):
     return ys, sides, rows, cols
 
 
-def multi_backward(grads, sides, rows, cols, lo, hi):
-    """STE backward of the tensors of a multi_forward in one launch; grads[i] may be None (that tensor is skipped)."""
+def multi_backward(grads, sides, rows, cols, lo, hi, inplace=None):
+    """STE backward of the tensors of a multi_forward in one launch; grads[i] may be None (that tensor is skipped).
+    inplace[i]: tensor i's gradient is masked where it stands and returned itself (weights; see train_backward)."""
     live = [i for i, g in enumerate(grads) if g is not None]
     out = [None] * len(grads)
+    inplace = inplace or [False] * len(grads)
     if not live:
         return out
     if len(live) == 1:
         i = live[0]
-        out[i] = train_backward(grads[i], sides[i], rows[i], cols, lo, hi)
+        out[i] = train_backward(grads[i], sides[i], rows[i], cols, lo, hi, inplace=inplace[i])
         return out
     code = _DTYPES.get(grads[live[0]].dtype)
     gs = {i: _aligned(grads[i]) for i in live}
     arr = (_lib.BwdTensor * len(live))()
     for j, i in enumerate(live):
-        out[i] = torch.empty_like(gs[i])
+        out[i] = gs[i] if inplace[i] else torch.empty_like(gs[i])
         sp = sides[i].data_ptr()
         arr[j] = _lib.BwdTensor(gs[i].data_ptr(), out[i].data_ptr(), rows[i], sp, sp + rows[i] * 8)
     g0 = gs[live[0]]
@@ -410,7 +416,7 @@ def multi_backward(grads, sides, rows, cols, lo, hi):
         rc = _lib.lib().fq_ste_bwd_mask_multi(len(live), arr, cols, float(lo), float(hi), code, 0, _stream(g0))
     if rc == _lib.ERR_UNSUPPORTED:
         for i in live:
-            out[i] = train_backward(gs[i], sides[i], rows[i], cols, lo, hi)
+            out[i] = train_backward(gs[i], sides[i], rows[i], cols, lo, hi, inplace=inplace[i])
         return out
     _lib.check(rc, "quantize_multi_backward")
     return out
@@ -427,11 +433,11 @@ def quantize_train(kind, x, num_bits, layerwise, lo, hi):
     return y, side[: rows * 8].view(torch.float32).view(rows, 2), side[rows * 8:]
 
 
-def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols):
+def ste_backward_mask(grad_output, lo, hi, row_bounds, mask, rows, cols, inplace=False):
     """STE backward from the (row_bounds, mask) a quantize_train call recorded -- x is not needed."""
     code = _prep(grad_output, "ste_backward_mask")
     g = _aligned(grad_output)  # a contiguous gradient can still be an offset view into a flat buffer
-    gx = torch.empty_like(g)
+    gx = g if inplace else torch.empty_like(g)
     if g.numel() == 0:
         return gx
     L = _lib.lib()

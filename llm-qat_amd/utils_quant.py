@@ -76,7 +76,8 @@ class _FakeQuantFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False):
+    def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False, inplace_grad=False):
+        ctx.fq_inplace = inplace_grad  # a QuantizeLinear's own weight: its gradient may be masked where it stands (point 6 below)
         if torch.compiler.is_compiling():  # Dynamo traces forward/backward of the Function: same kernels as custom ops (compiled.py)
             ctx.save_for_backward(input, clip_val)
             ctx.fq_mode = "compiled"
@@ -132,7 +133,7 @@ class _FakeQuantFunction(torch.autograd.Function):
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
             (side,) = ctx.saved_tensors
-            return ops.train_backward(grad_output, side, rows, cols, lo, hi), None, None, None
+            return ops.train_backward(grad_output, side, rows, cols, lo, hi, inplace=ctx.fq_inplace and _INPLACE_WGRAD), None, None, None
         saved = ctx.saved_tensors  # reference :83 / :158: (input, clip_val) [+ the row bounds in "bounds" mode]
         input, clip_val = saved[0], saved[1]
         lo, hi = _clip_pair(clip_val)
@@ -159,6 +160,15 @@ class _SymQuantizerOperand(_FakeQuantFunction):
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
         return _FakeQuantFunction._fwd("sym", ctx, input, clip_val, num_bits, layerwise, narrow=True)
+
+
+class _SymQuantizerWeight(_FakeQuantFunction):
+    """_SymQuantizerOperand for the WEIGHT of a QuantizeLinear: additionally, its gradient -- F.linear's fresh wgrad, which
+    no one else holds -- is masked where it stands and handed on by reference (no copy for rows that cannot clip)."""
+
+    @staticmethod
+    def forward(ctx, input, clip_val, num_bits, layerwise):
+        return _FakeQuantFunction._fwd("sym", ctx, input, clip_val, num_bits, layerwise, narrow=True, inplace_grad=True)
 
 
 class AsymQuantizer(_FakeQuantFunction):
@@ -209,6 +219,20 @@ _W12_FUSED = os.environ.get("LLMQAT_AMD_W12_FUSED", "0") == "1"
 def fuse_low_bit_mean(flag=True):
     global _W12_FUSED
     _W12_FUSED = bool(flag)
+
+
+# 6. A weight's rows practically never reach the STE clip, so its backward is the identity -- and the reference's
+#    `grad_output.clone()` (:84) exists only to be mutated by the two masked writes (:85-86).  For the WEIGHT operand of a
+#    QuantizeLinear the gradient that arrives is F.linear's freshly computed wgrad (the quantized weight has exactly one
+#    consumer, inside this module), owned by nobody else: it is masked where it stands (fq_ste_bwd_mask with gx == g; rows
+#    that cannot clip are not touched at all) and handed on by reference -- no 4 B/element copy per weight per step.
+#    Gradients of anything a caller can see (SymQuantizer.apply results, activations) are never touched in place.
+_INPLACE_WGRAD = os.environ.get("LLMQAT_AMD_INPLACE_WEIGHT_GRAD", "1") != "0"
+
+
+def inplace_weight_grad(flag=True):
+    global _INPLACE_WGRAD
+    _INPLACE_WGRAD = bool(flag)
 
 
 _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every call (:198, :245)
@@ -321,9 +345,10 @@ class _PairNode(torch.autograd.Function):
     """Autograd node over the results of one ops.pair_forward launch (weight and input of a QuantizeLinear)."""
 
     @staticmethod
-    def forward(ctx, weight, input, res, clip=(-2.0, 2.0)):
+    def forward(ctx, weight, input, res, clip=(-2.0, 2.0), weight_first=False):
         wq, xq, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
         ctx.dtype, ctx.clip = weight.dtype, clip
+        ctx.inplace_w = bool(weight_first)  # tensor 0 is a QuantizeLinear's weight: its gradient may be handed on by reference
         ctx.wide = wq.dtype != weight.dtype  # fp32 results under autocast (the K / V hooks): fp32 gradients come back
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
@@ -346,15 +371,15 @@ class _PairNode(torch.autograd.Function):
         if ctx.wide:
             gw, gx = (gw if need_w else None), (gx if need_x else None)
             if gw is None and gx is None:
-                return None, None, None, None
+                return None, None, None, None, None
             ow, ox = ops.pair_backward_wide(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
-            return ow, ox, None, None
+            return ow, ox, None, None, None
         gw = gw.to(ctx.dtype) if (need_w and gw is not None and gw.dtype != ctx.dtype) else (gw if need_w else None)
         gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
         if gw is None and gx is None:
-            return None, None, None, None
-        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi)
-        return ow, ox, None, None
+            return None, None, None, None, None
+        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=ctx.inplace_w and _INPLACE_WGRAD)
+        return ow, ox, None, None, None
 
 
 # 5. Sibling projections share their input (q/k/v: modeling_llama_quant.py:313,317,318; gate/up: :235) and all reduce over
@@ -399,7 +424,8 @@ class _MultiNode(torch.autograd.Function):
                 gs.append(None)
             else:
                 gs.append(g if g.dtype == ctx.dtype else g.to(ctx.dtype))
-        outs = ops.multi_backward(gs, list(ctx.saved_tensors), ctx.rows, ctx.cols, lo, hi)
+        inplace = [_INPLACE_WGRAD and i != 1 for i in range(len(gs))]  # tensor 1 is the shared input; the others are weights
+        outs = ops.multi_backward(gs, list(ctx.saved_tensors), ctx.rows, ctx.cols, lo, hi, inplace=inplace)
         return (None, None) + tuple(outs)
 
 
@@ -447,7 +473,7 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
         weight, row_bounds, ste_mask = ctx.saved_tensors
         if ste_mask is not None:
             rows, cols = ctx.rows_cols
-            return ops.ste_backward_mask(grad_output, lo, hi, row_bounds, ste_mask, rows, cols), None, None
+            return ops.ste_backward_mask(grad_output, lo, hi, row_bounds, ste_mask, rows, cols, inplace=_INPLACE_WGRAD), None, None
         bounds = row_bounds if grad_output.is_contiguous() and weight.is_contiguous() else None
         return ops.ste_backward(grad_output, weight, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols), None, None
 
@@ -490,7 +516,7 @@ class QuantizeLinear(nn.Linear):
         if pre is not None and pre[0] == self._prefetch_key():
             return pre[1]  # the leader of this sibling group quantized this weight in its own launch
         if not _WEIGHT_CACHE or not w.is_cuda:
-            return _SymQuantizerOperand.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
+            return _SymQuantizerWeight.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         ac = ops.autocast_active(w)
         key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics(), ac)
         ent = getattr(self, "_fq_wcache", None)
@@ -548,7 +574,7 @@ class QuantizeLinear(nn.Linear):
         if res is None:
             return None
         if grad and (self.weight.requires_grad or input_.requires_grad):
-            wq, xq = _PairNode.apply(self.weight, input_, res)
+            wq, xq = _PairNode.apply(self.weight, input_, res, (-2.0, 2.0), True)
         else:
             wq, xq = res[0], res[1]
         if key is not None:

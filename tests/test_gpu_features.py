@@ -877,3 +877,77 @@ def test_sibling_projections_share_one_launch(pkg, autocast):
     # launches per step: ungrouped 1 pair + 2 weights forward, the same backward = 6; grouped (from step 1 on) 1 + 1
     assert b[0][3] == 6 and b[2][3] == 6, (b[0][3], b[2][3])
     assert a[0][3] == 6 and a[1][3] == 2 and a[2][3] == 2, (a[0][3], a[1][3], a[2][3])
+
+
+# ------------------------------------------------------------------------------------------ weight gradients by reference
+def test_inplace_ste_backward_kernel(pkg):
+    """fq_ste_bwd_mask with gx == g: the gradient is masked where it stands; a tensor whose rows cannot clip is not touched
+    (bitwise unchanged), clippable rows get exactly the out-of-place result."""
+    ops = pkg.ops
+    g0 = torch.Generator(device="cuda").manual_seed(21)
+    for dt in (torch.bfloat16, torch.float32, torch.float16):
+        w = (torch.randn(300, 2048, generator=g0, device="cuda") * 0.02).to(dt)          # weight-like: no row reaches the clip
+        a = (torch.randn(300, 2048, generator=g0, device="cuda") * 1.2).to(dt)           # activation-like: every row does
+        mix = w.clone()
+        mix[7, 11], mix[7, 12], mix[200, 0] = 2.0, -3.5, 2.5                               # two clippable rows among safe ones
+        for x in (w, a, mix):
+            y, side, rows, cols = ops.train_forward("sym", x, 4, False, -2.0, 2.0)
+            g = torch.randn(300, 2048, generator=g0, device="cuda").to(dt)
+            want = ops.train_backward(g.clone(), side, rows, cols, -2.0, 2.0)
+            gi = g.clone()
+            got = ops.train_backward(gi, side, rows, cols, -2.0, 2.0, inplace=True)
+            assert got.data_ptr() == gi.data_ptr()                                         # handed on by reference
+            assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+            ref = torch.where((x >= 2) | (x <= -2), torch.zeros_like(g), g)
+            assert torch.equal(got, ref)
+    # pair + multi launches: the weight slots in place, the activation slot to a fresh tensor
+    xs = (torch.randn(64, 2048, generator=g0, device="cuda") * 1.3).bfloat16()
+    w2 = (torch.randn(128, 2048, generator=g0, device="cuda") * 0.02).bfloat16()
+    res = ops.multi_forward([mix.bfloat16(), xs, w2], [4, 8, 4], [True] * 3, -2.0, 2.0)
+    ys, sides, rows, cols = res
+    gs = [torch.randn_like(t) for t in (mix.bfloat16(), xs, w2)]
+    want = ops.multi_backward([g.clone() for g in gs], sides, rows, cols, -2.0, 2.0)
+    gi = [g.clone() for g in gs]
+    got = ops.multi_backward(gi, sides, rows, cols, -2.0, 2.0, inplace=[True, False, True])
+    assert got[0].data_ptr() == gi[0].data_ptr() and got[2].data_ptr() == gi[2].data_ptr() and got[1].data_ptr() != gi[1].data_ptr()
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    assert torch.equal(gi[1], gs[1])                                                       # the activation's incoming gradient is untouched
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_weight_gradient_by_reference_is_transparent(pkg, autocast):
+    """QuantizeLinear hands its weight's gradient on by reference (masked in place, default) -- same gradients, bit for
+    bit, as with inplace_weight_grad(False), for paired, grouped and separate-weight flows, incl. a weight that reaches the clip"""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+
+    def run(inplace, pairing):
+        torch.manual_seed(2)
+        mods = [QuantizeLinear(1024, 512, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(3)]
+        with torch.no_grad():
+            mods[1].weight[5, 9] = 2.25          # a weight element beyond the clip: its gradient must be zero
+        opt = torch.optim.SGD([m.weight for m in mods], lr=0.01)
+        pkg.inplace_weight_grad(inplace)
+        pkg.pair_operands(pairing)
+        out = []
+        try:
+            for step in range(2):
+                x = (torch.randn(2, 32, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(step)) * 1.4).bfloat16().requires_grad_(True)
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                    loss = qkv_loss(mods, x)
+                loss.backward()
+                out.append((loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods]))
+                opt.step()
+        finally:
+            pkg.inplace_weight_grad(True)
+            pkg.pair_operands(True)
+        return out
+
+    for pairing in (True, False):
+        a, b = run(True, pairing), run(False, pairing)
+        for (la, xa, wa), (lb, xb, wb) in zip(a, b):
+            assert torch.equal(la, lb) and torch.equal(xa, xb)
+            for p, q in zip(wa, wb):
+                assert torch.equal(p, q)
+            assert wa[1][5, 9] == 0

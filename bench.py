@@ -775,6 +775,8 @@ def main(argv=None):
         }
 
         def pair_traffic(k):
+            if "in place" in k:
+                return traffic.get("ste_bwd_pair_w4a8_inplace")
             if k in traffic:
                 return traffic[k]
             parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8")}.get(k)
@@ -794,7 +796,7 @@ def main(argv=None):
         out["kernels_step_out_of_place"] = [roofline_entry("ste_bwd_pair_w4a8 (both gradients to fresh tensors)", 2 * nb * BWD_BYTES_PER_ELEM,
                                                            wl.time_kernel(lambda s: wl.bwd_pair(s, inplace_w=False), it), traffic.get("ste_bwd_pair_w4a8"),
                                                            moved_bytes=bwd_w + bwd_a, traffic_source=tsrc)]
-        tw = wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it)
+        tw = (0.0, [0.0, 0.0, 0.0]) if args.core_extras else wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it)
         out["ste_bwd_w4_in_place"] = {"us_per_launch": round(tw[0] * 1e3, 2), "us_p10_p50_p90": [round(v * 1e3, 2) for v in tw[1]],
                                       "what": "fq_ste_bwd_mask with gx == g on the W4 tensor: every row's bounds prove nothing clips, the kernel exits "
                                               "before any vector memory operation (launch + 8 B per row)"}
@@ -823,9 +825,10 @@ def main(argv=None):
                                 "frac_algorithmic": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "frac_algorithmic_note": "10 B/elem reference-dataflow equivalent (SURVEY §8d), not a byte rate",
                                 "what": "both launches of one step: bytes moved / sum of launch times"}
-        out["unpaired_step"] = {"ms_per_step": round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
+        out["unpaired_step"] = {"ms_per_step": None if args.core_extras else round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
                                 "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2; weight gradient in place)"}
-        out["autograd_path"] = autograd_path(wl)
+        if not args.core_extras:
+            out["autograd_path"] = autograd_path(wl)
         # a live yardstick for "how fast can this device move the same bytes": ATen's device-to-device copy of the W tensor
         # (read 90.2 MB + write 90.2 MB = one single-tensor forward's algorithmic bytes), timed like the kernels above
         cmean, cpct = wl.time_kernel(lambda s: s["yw"].copy_(s["w"]), it)

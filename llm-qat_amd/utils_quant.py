@@ -510,6 +510,10 @@ class QuantizeLinear(nn.Linear):
         return (id(w), w._version, w.data_ptr(), self.w_bits, torch.is_grad_enabled() and w.requires_grad, _BACKWARD_MODE, ops.get_semantics(),
                 ops.autocast_active(w), _bwd_epoch[0])
 
+    def _wcache_key(self):
+        w = self.weight
+        return (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(w))
+
     def _quantized_weight(self):
         w = self.weight
         pre = self.__dict__.pop("_fq_prefetch", None)
@@ -518,7 +522,7 @@ class QuantizeLinear(nn.Linear):
         if not _WEIGHT_CACHE or not w.is_cuda:
             return _SymQuantizerWeight.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         ac = ops.autocast_active(w)
-        key = (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics(), ac)
+        key = self._wcache_key()
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:
             cached = ent[1]
@@ -550,8 +554,16 @@ class QuantizeLinear(nn.Linear):
 
     def _pair_forward(self, input_):
         """weight and input in one launch; None when the pair is not applicable (then the ordinary two calls run)"""
-        if not (_PAIR and _BACKWARD_MODE == "mask" and not _WEIGHT_CACHE and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
+        if not (_PAIR and _BACKWARD_MODE == "mask" and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
             return None
+        wkey = None
+        if _WEIGHT_CACHE:
+            # With the weight cache on, the FIRST use of a weight in a step still shares a launch with its input and fills the
+            # cache from it; the second use (the checkpoint recompute) finds the entry and launches nothing for the weight.
+            wkey = self._wcache_key()
+            ent = getattr(self, "_fq_wcache", None)
+            if ent is not None and ent[0] == wkey:
+                return None
         if self.act_quantizer is not SymQuantizer or self.act_layerwise or self.weight_layerwise:
             return None
         key = _act_key(_SymQuantizerOperand, input_, self.a_bits, False) if _SHARE_ACT else None
@@ -566,13 +578,18 @@ class QuantizeLinear(nn.Linear):
                         fl.append((weakref.ref(self), leader.weight._version))
                 return None
         grad = torch.is_grad_enabled()
-        multi = self._multi_forward(input_, key, grad) if (_GROUP and key is not None and self.__dict__.get("_fq_followers")) else None
+        multi = self._multi_forward(input_, key, grad) if (_GROUP and wkey is None and key is not None and self.__dict__.get("_fq_followers")) else None
         if multi is not None:
             return multi
         res = ops.pair_forward(self.weight, input_, self.w_bits, self.a_bits, -2.0, 2.0,
-                               grad and self.weight.requires_grad, grad and input_.requires_grad)
+                               (grad and self.weight.requires_grad) or wkey is not None, grad and input_.requires_grad)
         if res is None:
             return None
+        if wkey is not None:  # bounds + mask are recorded even without grad: the recompute pass's backward needs them
+            rows_w = res[4]
+            side_w = res[2]
+            self._fq_wcache = (wkey, (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:],
+                                      ops.rows_cols(tuple(self.weight.shape), False)))
         if grad and (self.weight.requires_grad or input_.requires_grad):
             wq, xq = _PairNode.apply(self.weight, input_, res, (-2.0, 2.0), True)
         else:

@@ -291,6 +291,38 @@ def _weight_quant_cache_body(pkg):
         pkg.enable_weight_quant_cache(False)
 
 
+@pytest.mark.parametrize("reentrant", [False, True])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_weight_quant_cache_keeps_operand_pairing(pkg, autocast, reentrant):
+    """the weight cache used to switch operand pairing off.  Now the first use of a weight in a step still shares
+    its launch with the input (and fills the cache from it); the recompute launches nothing for the weight.  Same results."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(QuantizeLinear(256, 512, w_bits=4, a_bits=8), torch.nn.SiLU(), QuantizeLinear(512, 256, w_bits=4, a_bits=8)).cuda().bfloat16()
+    with torch.no_grad():
+        net[0].weight[3, 5] = 2.5
+    xs = torch.randn(8, 256, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    names = ["pair_forward", "train_forward", "sym_quantize", "sym_forward_autocast", "quantize_train"]
+    for cache in (False, True):
+        pkg.enable_weight_quant_cache(cache)
+        try:
+            net.zero_grad(set_to_none=True)
+            x = xs.clone().requires_grad_(True)
+            with Counter(pkg.ops, names) as c, torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                out = checkpoint(net, x, use_reentrant=reentrant)
+                out.float().square().mean().backward()
+            res[cache] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()], c.n)
+        finally:
+            pkg.enable_weight_quant_cache(False)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    assert res[True][2][0][3, 5] == 0
+    # without the cache: 2 pair launches per pass x 2 passes = 4; with it: 2 pair launches in the first pass, then only the 2 activations
+    assert res[False][3] == 4 and res[True][3] == 4, (res[False][3], res[True][3])
+
+
 # ------------------------------------------------------------------------------------------ ABI claims
 def test_c_abi_calls_are_graph_capturable(pkg):
     """no allocation / sync inside the library: a forward+backward pair captures into a hipGraph and replays"""

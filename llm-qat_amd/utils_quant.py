@@ -478,6 +478,28 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
         return ops.ste_backward(grad_output, weight, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols), None, None
 
 
+class _PrecomputedAct(torch.autograd.Function):
+    """Autograd node over an activation that a paired launch has already fake-quantized (weight cache on): saves exactly
+    what _SymQuantizerOperand saves in mask mode (the side buffer), so a checkpointed forward that pairs and its recompute
+    that does not (the weight then comes from the cache) record the same tensors."""
+
+    @staticmethod
+    def forward(ctx, x, y, side, rows, cols, clip):
+        ctx.rows_cols, ctx.clip, ctx.dtype = (rows, cols), clip, x.dtype
+        ctx.save_for_backward(side)
+        return y.view_as(y)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        _bwd_epoch[0] += 1
+        (side,) = ctx.saved_tensors
+        lo, hi = ctx.clip
+        rows, cols = ctx.rows_cols
+        g = grad_output if grad_output.dtype == ctx.dtype else grad_output.to(ctx.dtype)
+        return ops.train_backward(g, side, rows, cols, lo, hi), None, None, None, None, None
+
+
 class QuantizeLinear(nn.Linear):
     def __init__(self, *kargs, symmetric=True, bias=False, w_bits=32, a_bits=32, act_layerwise=False,
                  weight_layerwise=False):
@@ -585,11 +607,19 @@ class QuantizeLinear(nn.Linear):
                                (grad and self.weight.requires_grad) or wkey is not None, grad and input_.requires_grad)
         if res is None:
             return None
-        if wkey is not None:  # bounds + mask are recorded even without grad: the recompute pass's backward needs them
-            rows_w = res[4]
-            side_w = res[2]
-            self._fq_wcache = (wkey, (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:],
-                                      ops.rows_cols(tuple(self.weight.shape), False)))
+        if wkey is not None:
+            # bounds + mask are recorded even without grad (the recompute pass's backward needs them), and the results are
+            # wrapped in the SAME nodes the recompute pass will build (_ReuseQuantizedWeight for the weight, a side-buffer
+            # node for the input), so non-reentrant checkpointing sees identical saved tensors in both passes
+            rows_w, rows_x, cols = res[4], res[5], res[6]
+            side_w, side_x = res[2], res[3]
+            cached = (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:], ops.rows_cols(tuple(self.weight.shape), False))
+            self._fq_wcache = (wkey, cached)
+            wq = _ReuseQuantizedWeight.apply(self.weight, cached, _CLIP) if (grad and self.weight.requires_grad) else res[0]
+            xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if (grad and input_.requires_grad) else res[1]
+            if key is not None:
+                _act_store(key, input_, xq, leader=self)
+            return wq, xq
         if grad and (self.weight.requires_grad or input_.requires_grad):
             wq, xq = _PairNode.apply(self.weight, input_, res, (-2.0, 2.0), True)
         else:

@@ -324,6 +324,23 @@ class ModelShapes:
                        b[gk].data_ptr(), b["gx"].data_ptr(), rows1, b["b"].data_ptr(), b["m"].data_ptr(), cols, -2.0, 2.0, code, st), "pair_bwd")
         return fn, sets
 
+    def entries_compact(self, iters, tag):
+        """the layer's dominant launches only (config 5: LLaMA-13B dimensions)"""
+        T, H, I = self.tokens, self.hidden, self.inter
+        torch = self.torch
+        out = []
+        for name, fn_sets, elems, fwd, mask_elems in (
+                (f"{tag} down_proj pair fwd: W4 [{H},{I}] + A8 [{T},{I}]", self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I),
+                (f"{tag} down_proj pair bwd (weight gradient in place)", self.pair_bwd(H, "w", T, "a", I, inplace0=True), T * I, False, T * I),
+                (f"{tag} q_proj pair fwd: W4 [{H},{H}] + A8 [{T},{H}]", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H),
+                (f"{tag} quantize_kv pair fwd: K4 + V4 [{T},{H}] x2", self.pair_fwd(T, "a", 4, T, "a", 4, H), 2 * T * H, True, 2 * T * H),
+                (f"{tag} W4 [{I},{H}] fwd (gate/up weight)", self.single_fwd(I, H, 4, "w"), I * H, True, 0)):
+            fn, sets = fn_sets
+            t = time_launches(torch, fn, iters, sets)
+            moved = elems * 4 + mask_elems // 8
+            out.append(roofline_entry(name, elems * (FWD_BYTES_PER_ELEM if fwd else BWD_BYTES_PER_ELEM), t, moved_bytes=moved))
+        return out
+
     def entries(self, iters):
         """one roofline entry per launch kind of the layer (name, what it is at the reference call site)"""
         T, H, I = self.tokens, self.hidden, self.inter
@@ -838,6 +855,7 @@ def main(argv=None):
         # the launches of one LLaMA-7B layer at their real shapes
         if not args.core_extras:
             out["kernels_model_shapes"] = ModelShapes(wl).entries(it)
+            out["kernels_model_shapes_13b"] = ModelShapes(wl, hidden=5120, inter=13824).entries_compact(max(10, it // 2), "13B")
         for hook in ([] if args.core_extras else EXTRA_ENTRIES):   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
             try:
                 out.update(hook(wl, it))

@@ -200,3 +200,67 @@ def test_quantize_linear_export_weight(ops):
     assert torch.equal(torch.where(d == 0, torch.zeros_like(d), d), torch.where(wq == 0, torch.zeros_like(wq), wq))
     with pytest.raises(ValueError):
         QuantizeLinear(64, 64, w_bits=2, a_bits=8).cuda().export_weight()
+
+
+def test_randomized_stress_round2_entry_points(ops):
+    """Randomized sweep over the round-2 entry points with adversarial content (NaN / Inf / zero rows, row magnitudes at the
+    ends of each dtype's range, odd widths, misaligned storage): packed export vs the oracle (bytes, scales, overflow
+    counts), multi-tensor launches and the in-place backward vs the single-tensor reference path.  LLMQAT_STRESS_TRIALS
+    scales it (default 90; 6000 trials verified on the final kernels)."""
+    import os
+    rng = np.random.default_rng(20261005)
+    col_choices = [1, 2, 3, 8, 24, 64, 100, 256, 264, 512, 1000, 1024, 2048, 4096, 4104, 8192, 11008, 16384, 20000]
+    for trial in range(int(os.environ.get("LLMQAT_STRESS_TRIALS", "90"))):
+        dtype = ["bf16", "fp32", "fp16"][trial % 3]
+        kind = "sym" if rng.random() < 0.6 else "asym"
+        rows, cols = int(rng.integers(1, 40)), int(rng.choice(col_choices))
+        bits = int(rng.choice([2, 3, 4, 6, 8, 12, 16])) if kind == "sym" else int(rng.choice([1, 2, 4, 8, 16]))
+        container = str(rng.choice(["int4", "int8", "int16"]))
+        scales = [1e-4, 0.02, 1.0, 3.0, 100.0]
+        if rng.random() < 0.25:
+            scales = {"fp32": [1e-42, 1e-38, 1e-30, 1e-19, 1e-10, 1e10, 1e19, 1e30, 1e38], "bf16": [1e-38, 1e-30, 1e-19, 1e-10, 1e10, 1e19, 1e30, 1e38],
+                      "fp16": [1e-7, 1e-6, 1e-5, 1e-3, 30.0, 1e3, 2e4, 6e4]}[dtype]
+        with np.errstate(over="ignore"):
+            x = rng.standard_normal((rows, cols)).astype(np.float32) * rng.choice(scales, size=(rows, 1)).astype(np.float32)
+        if rng.random() < 0.3:
+            x[rng.integers(0, rows), rng.integers(0, cols)] = rng.choice([np.nan, np.inf, -np.inf])
+        if rng.random() < 0.3:
+            x[rng.integers(0, rows)] = 0.0
+        xt = torch.from_numpy(x).to(TD[dtype])
+        x_np, xd = np_from(xt), xt.cuda()
+        if rng.random() < 0.2:      # contiguous but only element-aligned storage
+            flat = torch.empty(rows * cols + 1, dtype=TD[dtype], device="cuda")
+            flat[1:].copy_(xd.reshape(-1))
+            xd = flat[1:].view(rows, cols)
+        tag = f"trial {trial}: {kind} {dtype} [{rows},{cols}] b{bits} {container}"
+        e = ops.sym_export(xd, bits, container=container, autocast=False) if kind == "sym" else ops.asym_export(xd, bits, container=container)
+        ob, osc, oov = O.export(kind, x_np, rows, cols, bits, container, dtype)
+        raw = e.bins.contiguous().view(torch.uint8).reshape(rows, -1).cpu().numpy()
+        assert (raw == ob).all(), tag + f": {(raw != ob).sum()} bytes differ"
+        assert (e.overflow.cpu().numpy() == oov).all(), tag + " overflow"
+        got_sc = e.scales.cpu().numpy()
+        if kind == "asym":   # beta may differ in the sign of zero (-0.0 and +0.0 are equal minima)
+            got_sc, osc = got_sc.copy(), osc.copy()
+            got_sc[:, 1][got_sc[:, 1] == 0] = 0.0
+            osc[:, 1][osc[:, 1] == 0] = 0.0
+        assert bits_equal(got_sc, osc, "fp32"), tag + " scales"
+        if kind == "sym" and dtype != "fp32":
+            ea = ops.sym_export(xd, bits, container=container, autocast=True)
+            oba, osca, oova = O.export("sym", x_np, rows, cols, bits, container, dtype, autocast=True)
+            assert (ea.bins.contiguous().view(torch.uint8).reshape(rows, -1).cpu().numpy() == oba).all(), tag + " autocast bins"
+            assert (ea.overflow.cpu().numpy() == oova).all() and bits_equal(ea.scales.cpu().numpy(), osca, "fp32"), tag + " autocast scales"
+        # multi-tensor launch + in-place backward against the single-tensor path (Sym, aligned, register-resident shapes only)
+        if kind == "sym" and xd.data_ptr() % 16 == 0:
+            nt = int(rng.integers(2, 5))
+            ts = [xd] + [(torch.randn(int(rng.integers(1, 20)), cols, device="cuda") * float(rng.choice([0.02, 1.0, 5.0]))).to(TD[dtype]) for _ in range(nt - 1)]
+            bs = [max(bits, 2)] + [int(rng.choice([3, 4, 8])) for _ in range(nt - 1)]
+            res = ops.multi_forward(ts, bs, [True] * nt, -2.0, 2.0)
+            if res is not None:
+                ys, sides, rws, c = res
+                gs = [torch.randn_like(t) for t in ts]
+                inpl = [bool(rng.random() < 0.5) for _ in ts]
+                outs = ops.multi_backward([g.clone() for g in gs], sides, rws, c, -2.0, 2.0, inplace=inpl)
+                for t, b, y, g, o in zip(ts, bs, ys, gs, outs):
+                    y1, s1, r1, c1 = ops.train_forward("sym", t, b, False, -2.0, 2.0)
+                    assert torch.equal(y.view(torch.uint8), y1.view(torch.uint8)), tag + " multi fwd"
+                    assert torch.equal(o.view(torch.uint8), ops.train_backward(g.clone(), s1, r1, c1, -2.0, 2.0).view(torch.uint8)), tag + " multi bwd"

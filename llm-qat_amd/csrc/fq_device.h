@@ -359,6 +359,20 @@ __device__ __forceinline__ uint32_t asym_chain(float (&f)[Ty<DT>::EPD], const As
     return T::pack(f);
 }
 
+// The two halves of that chain, for the lookup-table form of the register kernel (16-bit tensors, bits <= 8): everything
+// up to the bin index depends on the element, everything after it only on (bin, row) -- at most 256 values per row.
+template <int DT, bool FAST> __device__ __forceinline__ float asym_first_half(float x, const AsymRow& r, const AsymConst& k) {
+    using T = Ty<DT>;
+    const float d = T::rb(x - r.mn);
+    const float n = T::rb(FAST ? d * r.ra : (r.mk ? div_exact(d, r.a, r.ra) : d / r.a));
+    return __builtin_rintf(T::rb(n * k.S));
+}
+template <int DT, bool FAST> __device__ __forceinline__ float asym_second_half(float q, const AsymRow& r, const AsymConst& k) {
+    using T = Ty<DT>;
+    const float w = T::rb((FAST || k.mul_inv) ? q * k.invS : div_exact(q, k.S, k.invS));
+    return T::rb(T::rb(w * r.a) + r.mn);
+}
+
 template <int DT, bool FAST = false>
 __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, const AsymConst& k, int32_t* idx) {
     float f[Ty<DT>::EPD];

@@ -202,6 +202,10 @@ template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, 
         // bit-identical after the bf16 rounding (DESIGN.md "Numerics").
         if (fast) return asym ? rowwise_t<DT, true, true>(a, ws, wsb, st) : rowwise_t<DT, false, true>(a, ws, wsb, st);
     }
+    if constexpr (DT == F16) {
+        // fp16 AsymQuantizer at <= 8 bits: FAST selects the lookup-table form of the register kernel (exact arithmetic kept)
+        if (fast && asym) return rowwise_t<DT, true, true>(a, ws, wsb, st);
+    }
     return asym ? rowwise_t<DT, true, false>(a, ws, wsb, st) : rowwise_t<DT, false, false>(a, ws, wsb, st);
 }
 

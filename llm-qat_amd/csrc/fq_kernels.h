@@ -129,6 +129,13 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     constexpr int EPV = 16 / T::ESIZE;
     constexpr int NW = TPR / 64;
     __shared__ uint32_t red[3][NW > 1 ? NW : 1];
+    // AsymQuantizer on 16-bit tensors at <= 8 bits (FAST): the chain behind the bin index -- three of its six roundings --
+    // depends only on (bin, row), so each row tabulates its <= 256 dequantized values in LDS once and the elementwise pass
+    // ends in a lookup: 16 -> ~10 VALU instructions per element (the kernel is VALU-bound on mid-sized tensors).  bf16
+    // additionally uses its reciprocal-multiply identities (AFAST); fp16 keeps the exact divisions.
+    constexpr bool ALUT = ASYM && FAST && T::ESIZE == 2 && !DBG;
+    constexpr bool AFAST = FAST && DT == BF16;
+    __shared__ uint16_t lut[ALUT ? (TPR == 64 ? 4 : 1) : 1][ALUT ? 256 : 1];
 
     int64_t row;
     int t;
@@ -231,6 +238,23 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             }
         }
     }
+    // A row with a NaN / Inf among {alpha + 1e-8, beta} has NaN bins: it takes the plain chain (wave-uniform).
+    bool use_lut = false;
+    if constexpr (ALUT) {
+        use_lut = (ar.a - ar.a == 0.0f) && (ar.mn - ar.mn == 0.0f);
+        if (use_lut) {
+            uint16_t* L = lut[TPR == 64 ? (threadIdx.x >> 6) : 0];
+            const int nbins = (int)a.asym.S + 1;  // <= 256
+            for (int i = t; i < nbins; i += TPR) {
+                float y[2] = {asym_second_half<DT, AFAST>((float)i, ar, a.asym), 0.f};
+                L[i] = (uint16_t)T::pack(y);
+            }
+        }
+        // the row's own threads wrote the table: one wave (TPR == 64) sees its LDS writes in order; a workgroup needs the
+        // barrier (use_lut is uniform over the row's threads, but the barrier is taken unconditionally)
+        if constexpr (NW > 1) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 
     // Elementwise pass.  Rows that can actually be clipped also emit the STE bit mask for the backward.
     const bool want_mask = msk && !((ub < a.hi) && (lb > a.lo));  // wave-uniform
@@ -278,7 +302,17 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             for (int k = 0; k < T::EPD; ++k) fd[k] = f[d * T::EPD + k];
             int32_t* ip = (DBG && idxr) ? ib + d * T::EPD : nullptr;
             if constexpr (!ASYM) o[d] = sym_chain<DT, FAST>(fd, sr, ip);
-            else o[d] = asym_chain<DT, FAST>(fd, ar, a.asym, ip);
+            else if constexpr (ALUT) {
+                if (use_lut) {
+                    const uint16_t* L = lut[TPR == 64 ? (threadIdx.x >> 6) : 0];
+                    // p + 1.5 * 2^23: the (already integral) bin as an integer in the low mantissa bits
+                    const uint32_t i0 = as_u(asym_first_half<DT, AFAST>(fd[0], ar, a.asym) + 12582912.0f) & 0xFFu;
+                    const uint32_t i1 = as_u(asym_first_half<DT, AFAST>(fd[1], ar, a.asym) + 12582912.0f) & 0xFFu;
+                    o[d] = (uint32_t)L[i0] | ((uint32_t)L[i1] << 16);
+                } else {
+                    o[d] = asym_chain<DT, AFAST>(fd, ar, a.asym, ip);
+                }
+            } else o[d] = asym_chain<DT, FAST && DT == BF16>(fd, ar, a.asym, ip);
         }
         if (v < nvec) {
             st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
@@ -652,15 +686,15 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
             uint4 o;
             int32_t ib[EPV];
             if constexpr (!ASYM) {
-                o.x = sym_dword<DT, FAST>(r[i].x, sr, idxr ? ib + 0 * T::EPD : nullptr);
-                o.y = sym_dword<DT, FAST>(r[i].y, sr, idxr ? ib + 1 * T::EPD : nullptr);
-                o.z = sym_dword<DT, FAST>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
-                o.w = sym_dword<DT, FAST>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
+                o.x = sym_dword<DT, FAST && DT == BF16>(r[i].x, sr, idxr ? ib + 0 * T::EPD : nullptr);
+                o.y = sym_dword<DT, FAST && DT == BF16>(r[i].y, sr, idxr ? ib + 1 * T::EPD : nullptr);
+                o.z = sym_dword<DT, FAST && DT == BF16>(r[i].z, sr, idxr ? ib + 2 * T::EPD : nullptr);
+                o.w = sym_dword<DT, FAST && DT == BF16>(r[i].w, sr, idxr ? ib + 3 * T::EPD : nullptr);
             } else {
-                o.x = asym_dword<DT, FAST>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
-                o.y = asym_dword<DT, FAST>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
-                o.z = asym_dword<DT, FAST>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
-                o.w = asym_dword<DT, FAST>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
+                o.x = asym_dword<DT, FAST && DT == BF16>(r[i].x, ar, a.asym, idxr ? ib + 0 * T::EPD : nullptr);
+                o.y = asym_dword<DT, FAST && DT == BF16>(r[i].y, ar, a.asym, idxr ? ib + 1 * T::EPD : nullptr);
+                o.z = asym_dword<DT, FAST && DT == BF16>(r[i].z, ar, a.asym, idxr ? ib + 2 * T::EPD : nullptr);
+                o.w = asym_dword<DT, FAST && DT == BF16>(r[i].w, ar, a.asym, idxr ? ib + 3 * T::EPD : nullptr);
             }
             if (v < nvec) {
                 yr[v] = o;
@@ -675,7 +709,7 @@ __global__ __launch_bounds__(TP_THREADS) void apply_kernel(RowArgs a, const uint
             const float v = T::load1(a.x, base + c);
             int32_t* ip = a.idx ? a.idx + base + c : nullptr;
             float o;
-            if constexpr (!ASYM) o = sym_elem<DT, FAST>(v, sr, ip);
+            if constexpr (!ASYM) o = sym_elem<DT, FAST && DT == BF16>(v, sr, ip);
             else o = asym_elem<DT>(v, ar, a.asym, ip);
             T::store1(a.y, base + c, o);
         }

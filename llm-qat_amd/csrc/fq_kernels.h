@@ -129,11 +129,12 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     constexpr int EPV = 16 / T::ESIZE;
     constexpr int NW = TPR / 64;
     __shared__ uint32_t red[3][NW > 1 ? NW : 1];
-    // AsymQuantizer on 16-bit tensors at <= 8 bits (FAST): the chain behind the bin index -- three of its six roundings --
-    // depends only on (bin, row), so each row tabulates its <= 256 dequantized values in LDS once and the elementwise pass
-    // ends in a lookup: 16 -> ~10 VALU instructions per element (the kernel is VALU-bound on mid-sized tensors).  bf16
-    // additionally uses its reciprocal-multiply identities (AFAST); fp16 keeps the exact divisions.
-    constexpr bool ALUT = ASYM && FAST && T::ESIZE == 2 && !DBG;
+    // AsymQuantizer on fp16 tensors at <= 8 bits (FAST): the chain behind the bin index -- three of its six roundings and one
+    // of its two exact divisions -- depends only on (bin, row), so each row tabulates its <= 256 dequantized values in LDS
+    // once and the elementwise pass ends in a lookup.  Measured (tools/shape_sweep.py): fp16 [4096,11008] 43 -> 34 us,
+    // [2048,11008] 24.0 -> 21.4 us.  bf16 keeps the arithmetic chain: its divisions are already reciprocal multiplies
+    // (AFAST) and the eight 2-byte LDS reads per vector cost what the saved VALU gains (19.4 -> 20.3 us with the table).
+    constexpr bool ALUT = ASYM && FAST && DT == F16 && !DBG;
     constexpr bool AFAST = FAST && DT == BF16;
     __shared__ uint16_t lut[ALUT ? (TPR == 64 ? 4 : 1) : 1][ALUT ? 256 : 1];
 
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     // A row with a NaN / Inf among {alpha + 1e-8, beta} has NaN bins: it takes the plain chain (wave-uniform).
     bool use_lut = false;
     if constexpr (ALUT) {
-        use_lut = (ar.a - ar.a == 0.0f) && (ar.mn - ar.mn == 0.0f);
+        // ... as does a row with alpha + 1e-8 == 0 (1e-8 rounds to 0 in fp16: a constant row divides 0 by 0)
+        use_lut = (ar.a - ar.a == 0.0f) && (ar.mn - ar.mn == 0.0f) && ar.a > 0.0f;
         if (use_lut) {
             uint16_t* L = lut[TPR == 64 ? (threadIdx.x >> 6) : 0];
             const int nbins = (int)a.asym.S + 1;  // <= 256

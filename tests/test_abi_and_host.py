@@ -164,3 +164,72 @@ def test_reciprocal_multiply_with_correction_equals_ieee_division(tmp_path):
     subprocess.run(["gcc", "-O2", "-mfma", "-o", exe, os.path.join(ROOT, "tests", "c_host", "markstein_check.c"), "-lm"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+# ---- round 2 host logic (no kernel is launched) ------------------------------------------------------------------------
+def test_export_container_rules_and_host_side_unpacking():
+    """ops.default_container picks the smallest LOSSLESS container (8-bit bf16 needs int16: the reference has no clamp and
+    reaches bin +128); QuantExport.unpacked / .dequantize (pure torch host code) reproduce the reference's `idx` / `y`
+    fixtures when fed the oracle's packed bytes -- on CPU tensors, no GPU involved."""
+    import numpy as np
+    import torch
+    from conftest import golden, bits_equal
+    from oracle import oracle as O
+    import llm_qat_amd
+    ops = llm_qat_amd.ops
+    assert ops.default_container("sym", 4, torch.bfloat16) == "int4" and ops.default_container("sym", 3, torch.float32) == "int4"
+    assert ops.default_container("sym", 8, torch.bfloat16) == "int16" and ops.default_container("sym", 8, torch.float16) == "int8"
+    assert ops.default_container("sym", 7, torch.bfloat16) == "int8" and ops.default_container("sym", 16, torch.float32) == "int16"
+    assert ops.default_container("asym", 4, torch.bfloat16) == "int4" and ops.default_container("asym", 8, torch.bfloat16) == "int8"
+    TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+    n = 0
+    for kind in ("sym", "asym"):
+        G = golden(f"{kind}_fwd.npz")
+        for c in G.cases[::3]:
+            dt, bits = c["dtype"], c["bits"]
+            rows, cols = O.rows_cols(c["shape"], c["layerwise"])
+            for container in ("int4", "int8", "int16"):
+                ob, osc, oov = O.export(kind, G.arr(c, "x"), rows, cols, bits, container, dt)
+                raw = torch.from_numpy(ob.copy())
+                if container == "int8":
+                    bins = (raw.view(torch.int8) if kind == "sym" else raw).view(rows, cols)
+                elif container == "int16":
+                    bins = raw.view(torch.int16).view(rows, cols)
+                else:
+                    bins = raw
+                e = ops.QuantExport(kind=kind, bins=bins, scales=torch.from_numpy(osc.copy()), overflow=torch.from_numpy(oov.copy()), container=container,
+                                    num_bits=bits, shape=(rows, cols), rows=rows, cols=cols, dtype=TD[dt])
+                assert (e.unpacked().numpy() == O.unpack_bins(ob, cols, container, kind == "sym")).all(), (c["name"], container)
+                ok = oov == 0
+                if not ok.any():
+                    continue
+                y = e.dequantize()
+                got = y.numpy() if dt == "fp32" else y.view(torch.int16).numpy().view(np.uint16)
+                want = G.arr(c, "y").reshape(rows, cols)
+                zero = (lambda a: np.where(a == 0, 0, a)) if dt == "fp32" else (lambda a: np.where((a & 0x7FFF) == 0, 0, a))
+                assert bits_equal(zero(got[ok]), zero(want[ok]), dt), (c["name"], container)
+                n += 1
+    assert n > 100
+
+
+def test_round2_entry_points_validate_arguments_without_a_gpu():
+    import ctypes
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    assert L.fq_export_bins_bytes(4, 63, _lib.BINS_INT4) == 4 * 32 and L.fq_export_bins_bytes(0, 63, _lib.BINS_INT4) == 0
+    assert L.fq_export_bins_bytes(4, 64, 7) == 0
+    bad = ctypes.c_void_p(16)
+    assert L.fq_sym_export(bad, None, None, None, 4, 64, 8, _lib.BINS_INT8, 1, 0, 0, None) == -4          # bins NULL
+    assert L.fq_sym_export(bad, bad, None, None, 4, 64, 8, _lib.BINS_NONE, 1, 0, 0, None) == -7           # needs a container
+    assert L.fq_sym_export(bad, bad, None, None, 4, 64, 40, _lib.BINS_INT8, 1, 0, 0, None) == -2          # bits
+    assert L.fq_sym_export(bad, bad, None, None, 4, 64, 8, _lib.BINS_INT8, 0, 0, 1, None) == -1           # autocast on fp32
+    assert L.fq_asym_export(bad, bad, None, None, 0, 64, 8, _lib.BINS_INT8, 1, 0, None) == 0              # empty: nothing to do
+    assert L.fq_sym_row_scales(bad, None, 4, 64, 8, 1, 0, 0, -2.0, 2.0, None, None, 0, None) == -4        # nothing to produce
+    assert L.fq_qlinear_fwd(bad, None, bad, None, bad, 8, 100, 16, 1, 0, None, None, 0, None) == -8       # in_features % 64
+    assert L.fq_qlinear_fwd(bad, None, bad, None, bad, 8, 128, 16, 0, 0, None, None, 0, None) == -1       # bf16 only
+    assert L.fq_qlinear_fwd(bad, None, bad, None, bad, 0, 128, 16, 1, 0, None, None, 0, None) == 0        # no tokens
+    t = (_lib.FwdTensor * 5)()
+    assert L.fq_sym_fwd_multi(5, t, 64, 1, 0, 0, -2.0, 2.0, None) == -7                                   # at most 4 tensors
+    assert L.fq_sym_fwd_multi(2, t, 64, 1, 0, 0, -2.0, 2.0, None) in (-2, -3, -4)                         # zeroed descriptors are rejected
+    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, 0, None) == -2
+    assert b"bits" in L.fq_last_error() or b"w_bits" in L.fq_last_error()

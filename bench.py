@@ -324,6 +324,28 @@ class ModelShapes:
                        b[gk].data_ptr(), b["gx"].data_ptr(), rows1, b["b"].data_ptr(), b["m"].data_ptr(), cols, -2.0, 2.0, code, st), "pair_bwd")
         return fn, sets
 
+    def group_launch(self, specs, cols, backward=False, inplace=()):
+        """a sibling group in ONE launch (fq_sym_fwd_multi / fq_ste_bwd_mask_multi): specs = [(rows, style, bits), ...]"""
+        L, lib_, st = self.L, self._lib, self.wl.stream
+        code = lib_.DTYPE_BF16
+        per = [self.sets_for(r, cols, style + f"g{i}") for i, (r, style, _) in enumerate(specs)]
+        sets = [dict(t=list(ts)) for ts in zip(*per)]
+        n = len(specs)
+
+        def fwd(s):
+            arr = (lib_.FwdTensor * n)()
+            for i, (d, (r, _, bits)) in enumerate(zip(s["t"], specs)):
+                arr[i] = lib_.FwdTensor(d["x"].data_ptr(), d["y"].data_ptr(), r, bits, d["b"].data_ptr(), d["m"].data_ptr(), d["mb"])
+            self.chk(L.fq_sym_fwd_multi(n, arr, cols, code, 0, 0, -2.0, 2.0, st), "fq_sym_fwd_multi")
+
+        def bwd(s):
+            arr = (lib_.BwdTensor * n)()
+            for i, (d, (r, _, _)) in enumerate(zip(s["t"], specs)):
+                arr[i] = lib_.BwdTensor(d["g"].data_ptr(), (d["g"] if i in inplace else d["gx"]).data_ptr(), r, d["b"].data_ptr(), d["m"].data_ptr())
+            self.chk(L.fq_ste_bwd_mask_multi(n, arr, cols, -2.0, 2.0, code, 0, st), "fq_ste_bwd_mask_multi")
+
+        return (bwd if backward else fwd), sets
+
     def entries_compact(self, iters, tag):
         """the layer's dominant launches only (config 5: LLaMA-13B dimensions)"""
         T, H, I = self.tokens, self.hidden, self.inter
@@ -368,10 +390,18 @@ class ModelShapes:
             self.pair_fwd(T, "a", 4, T, "a", 4, H, autocast=2), 2 * T * H, True, 2 * T * H, bpe_in=2, bpe_out=4)
         add("q_proj pair fwd: W4 [4096,4096] + A8 [2048,4096]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H)
         add("W4 [11008,4096] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True)
+        qkv = [(H, "w", 4), (T, "a", 8), (H, "w", 4), (H, "w", 4)]
+        add("q/k/v group fwd in ONE launch: W4 [4096,4096] x3 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:313,317,318 (sibling group)",
+            self.group_launch(qkv, H), (3 * H + T) * H, True, T * H)
+        gu = [(I, "w", 4), (T, "a", 8), (I, "w", 4)]
+        add("gate/up group fwd in ONE launch: W4 [11008,4096] x2 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:235 (sibling group)",
+            self.group_launch(gu, H), (2 * I + T) * H, True, T * H)
         # backward launches (their forwards above have filled bounds + masks of the same buffers)
         add("down_proj pair bwd (weight gradient in place: product default)", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I, inplace0=True),
             T * I, False, T * I)
         add("down_proj pair bwd, both gradients to fresh tensors", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I)
+        add("q/k/v group bwd in ONE launch (weight gradients in place)", "utils_quant.py:77-87 x4", self.group_launch(qkv, H, backward=True, inplace=(0, 2, 3)),
+            T * H, False, T * H)
         add("A8 [2048,4096] bwd", "utils_quant.py:77-87", self.single_bwd(T, H, "a"), T * H, False, T * H)
         add("quantize_kv pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(T, "a", T, "a", H), 2 * T * H, False, 2 * T * H)
         add("quantize_kv pair bwd under autocast: fp32 grads in, bf16 out", "utils_quant.py:77-87 x2 + the engine's cast",

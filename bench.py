@@ -267,7 +267,7 @@ class ModelShapes:
         g = torch.Generator(device=dev).manual_seed(4321 + rows + cols)
         sets = []
         for _ in range(nsets):
-            x = (torch.randn(rows, cols, generator=g, device=dev) * 0.02).bfloat16() if style == "w" else _act_like(torch, rows, cols, g, dev)
+            x = (torch.randn(rows, cols, generator=g, device=dev) * 0.02).bfloat16() if style.startswith("w") else _act_like(torch, rows, cols, g, dev)
             d = dict(x=x, y=torch.empty_like(x), g=(torch.randn(rows, cols, generator=g, device=dev) * 1e-3).bfloat16(), gx=torch.empty_like(x),
                      b=torch.empty(rows, 2, device=dev), m=torch.empty(max(mb, 8), dtype=torch.uint8, device=dev), mb=mb)
             if want_y32:

@@ -716,9 +716,10 @@ def init_ranks(args):
         if ndev < 1:
             raise SystemExit("bench.py: no GPU visible")
         if world > ndev:
-            if os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1" or backend == "nccl":
+            if os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1":
                 raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible. One process per GPU is the contract; "
-                                 f"a rehearsal that shares GPUs needs BENCH_ALLOW_SHARED_GPU=1 and BENCH_DIST_BACKEND=gloo")
+                                 f"a rehearsal that shares GPUs needs BENCH_ALLOW_SHARED_GPU=1 (RCCL refuses two ranks on one device: "
+                                 f"the timing barrier then falls back to gloo, or set BENCH_DIST_BACKEND=gloo)")
             info["ranks_share_devices"] = True
         device = torch.device("cuda", local_rank % ndev)
         torch.cuda.set_device(device)
@@ -729,10 +730,34 @@ def init_ranks(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("BENCH_INIT_TIMEOUT_S", "300"))))
-        t = torch.ones(1, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t)   # every rank that joined adds 1
-        info["ranks_seen"] = int(t.item())
+        tmo = datetime.timedelta(seconds=int(os.environ.get("BENCH_INIT_TIMEOUT_S", "300")))
+
+        def join(bk, init_method=None):
+            if init_method:   # the fallback's own rendezvous: rank 0 hosts it, whatever launcher started us
+                dist.init_process_group(bk, init_method=init_method, rank=rank, world_size=world, timeout=tmo)
+            else:
+                dist.init_process_group(bk, timeout=tmo)
+            t = torch.ones(1, device=device if bk == "nccl" else "cpu")
+            dist.all_reduce(t)   # every rank that joined adds 1 (RCCL builds its communicator here: a failure shows up now)
+            return int(t.item())
+
+        try:
+            info["ranks_seen"] = join(backend)
+        except Exception as e:  # noqa: BLE001
+            # The data path has no collective: the group only carries the timing barrier and a max over ranks.  If RCCL cannot
+            # start on this node, that is no reason to lose the scaling point -- but the switch must be COLLECTIVE: the first
+            # all-reduce fails or succeeds on every rank alike, and the gloo group meets on its own rendezvous (MASTER_PORT + 1),
+            # so no rank can end up in a different backend.  An explicitly requested backend is never replaced.
+            if backend != "nccl" or "BENCH_DIST_BACKEND" in os.environ:
+                raise
+            print(f"bench.py: rank {rank}: RCCL process group failed ({e!r}); every rank falls back to gloo for the timing barrier", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            backend = "gloo"
+            info["dist_backend_fallback"] = f"nccl failed: {e!r}"[:300]
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+            info["ranks_seen"] = join(backend, f"tcp://{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{port}")
         info["dist_backend"] = backend
         if info["ranks_seen"] != args.gpus:
             raise SystemExit(f"bench.py: {info['ranks_seen']} ranks joined, --gpus {args.gpus} asked for")

@@ -393,13 +393,13 @@ template <int DT, int WBITS> __device__ __forceinline__ float w12_elem(float w, 
     float q;
     if constexpr (WBITS == 1) {
         const float sg = (t > 0.f) ? 1.f : (t < 0.f) ? -1.f : 0.f;
-        q = T::rb(sc * sg);
+        q = sc * sg;  // sc * {-1, 0, 1}: exact, the reference's rounding of it is the identity
     } else {
         const float c = (t != t) ? t : __builtin_fminf(__builtin_fmaxf(t, -cv), cv);
-        float u = T::rb(T::rb(c) * 2.0f);
+        float u = T::rb(c) * 2.0f;  // |c| <= 0.99: doubling a dtype value is exact, rounding it again the identity
         u = T::rb(u - 0.5f);
-        u = __builtin_rintf(u);
-        u = T::rb(u + 0.5f);
+        u = __builtin_rintf(u);     // in {-2, -1, 0, 1} (or NaN)
+        u = u + 0.5f;               // {-1.5, -0.5, 0.5, 1.5}: exact in every dtype
         u = T::rb(sc * u);
         q = T::rb(u / 2.0f);
     }

@@ -206,7 +206,7 @@ def test_randomized_stress_round2_entry_points(ops):
     """Randomized sweep over the round-2 entry points with adversarial content (NaN / Inf / zero rows, row magnitudes at the
     ends of each dtype's range, odd widths, misaligned storage): packed export vs the oracle (bytes, scales, overflow
     counts), multi-tensor launches and the in-place backward vs the single-tensor reference path.  LLMQAT_STRESS_TRIALS
-    scales it (default 90; 6000 trials verified on the final kernels)."""
+    scales it (default 90; 20 000 trials verified on the final kernels)."""
     import os
     rng = np.random.default_rng(20261005)
     col_choices = [1, 2, 3, 8, 24, 64, 100, 256, 264, 512, 1000, 1024, 2048, 4096, 4104, 8192, 11008, 16384, 20000]

@@ -20,7 +20,11 @@ the same step on its own GPU, no data-path collective; value = N * per-rank elem
 anything touches a GPU; under `python -m torch.distributed.run` it joins the ranks the launcher started.
 A request for N ranks never reports fewer: if a rank is missing the run exits non-zero.
 
-Extra objects on the JSON line (every `frac` is a byte RATE the kernel sustained / 8 TB/s, never > 1):
+Output (round 3): the LAST stdout line is a compact headline (< 4 KB: the contract's keys + `roofline`, `roofline_step`,
+`cpu_baseline`, `value_out_of_place`) -- the driver keeps an 8 KB stdout tail, and round 2's single 27 KB line was cut.
+Every other family below is printed as its own earlier stdout line ({"bench_extras": <family>, "data": ...}) and the whole
+record is written to bench_extras.json next to this file.
+Families (every `frac` is a byte RATE the kernel sustained / 8 TB/s, never > 1):
   roofline      dominant kernel (the step's forward launch): algorithmic bytes / live HIP-event launch time vs 8 TB/s
   kernels_step  both launches of the step;  kernels  the four single-tensor launches
   kernels_model_shapes   the quantizer launches of one LLaMA-7B layer at their real shapes
@@ -197,6 +201,14 @@ class Workload:
         self.fwd_pair(sf)
         self.bwd_pair(sb)
 
+    def step_out_of_place(self, i):
+        # the like-for-like step (the reference's data flow, utils_quant.py:83-87 `grad_output.clone()`): BOTH gradients are
+        # written to fresh tensors, as round 1 measured it and as SymQuantizer.apply does for any caller-visible gradient
+        sf = self.sets[i % self.nsets]
+        sb = self.sets[(i + self.nsets - 2) % self.nsets]
+        self.fwd_pair(sf)
+        self.bwd_pair(sb, inplace_w=False)
+
     def step_unpaired(self, i):
         sf = self.sets[i % self.nsets]
         sb = self.sets[(i + self.nsets - 2) % self.nsets]
@@ -346,67 +358,76 @@ class ModelShapes:
 
         return (bwd if backward else fwd), sets
 
-    def entries_compact(self, iters, tag):
+    def _spec(self, name, site, fn_sets, elems, fwd, extra_mask_elems=0, bpe_in=2, bpe_out=2):
+        """one launch kind of the layer: what it is at the reference call site, the launch, its rotating buffers, and its
+        byte counts (algorithmic = SURVEY §8d accounting; moved = what the kernel touches by design, incl. mask bits)"""
+        fn, sets = fn_sets
+        moved = elems * (bpe_in + bpe_out) + extra_mask_elems // 8
+        algo = elems * (FWD_BYTES_PER_ELEM if fwd else BWD_BYTES_PER_ELEM) if (bpe_in, bpe_out) == (2, 2) else moved
+        return dict(name=name, site=site, fn=fn, sets=sets, algo=algo, moved=moved)
+
+    def specs_compact(self, tag):
         """the layer's dominant launches only (config 5: LLaMA-13B dimensions)"""
         T, H, I = self.tokens, self.hidden, self.inter
-        torch = self.torch
-        out = []
-        for name, fn_sets, elems, fwd, mask_elems in (
-                (f"{tag} down_proj pair fwd: W4 [{H},{I}] + A8 [{T},{I}]", self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I),
-                (f"{tag} down_proj pair bwd (weight gradient in place)", self.pair_bwd(H, "w", T, "a", I, inplace0=True), T * I, False, T * I),
-                (f"{tag} q_proj pair fwd: W4 [{H},{H}] + A8 [{T},{H}]", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H),
-                (f"{tag} quantize_kv pair fwd: K4 + V4 [{T},{H}] x2", self.pair_fwd(T, "a", 4, T, "a", 4, H), 2 * T * H, True, 2 * T * H),
-                (f"{tag} W4 [{I},{H}] fwd (gate/up weight)", self.single_fwd(I, H, 4, "w"), I * H, True, 0)):
-            fn, sets = fn_sets
-            t = time_launches(torch, fn, iters, sets)
-            moved = elems * 4 + mask_elems // 8
-            out.append(roofline_entry(name, elems * (FWD_BYTES_PER_ELEM if fwd else BWD_BYTES_PER_ELEM), t, moved_bytes=moved))
-        return out
+        S = self._spec
+        return [
+            S(f"{tag} down_proj pair fwd: W4 [{H},{I}] + A8 [{T},{I}]", "utils_quant.py:195-201,:244-248", self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I),
+            S(f"{tag} down_proj pair bwd (weight gradient in place)", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I, inplace0=True), T * I, False, T * I),
+            S(f"{tag} q_proj pair fwd: W4 [{H},{H}] + A8 [{T},{H}]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H),
+            S(f"{tag} quantize_kv pair fwd: K4 + V4 [{T},{H}] x2", "modeling_llama_quant.py:320-327", self.pair_fwd(T, "a", 4, T, "a", 4, H), 2 * T * H, True, 2 * T * H),
+            S(f"{tag} W4 [{I},{H}] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True, 0)]
+
+    def specs(self):
+        """one spec per launch kind of the layer, in an order where every backward finds the bounds + masks its forward left"""
+        T, H, I = self.tokens, self.hidden, self.inter
+        S = self._spec
+        qkv = [(H, "w", 4), (T, "a", 8), (H, "w", 4), (H, "w", 4)]
+        gu = [(I, "w", 4), (T, "a", 8), (I, "w", 4)]
+        return [
+            # forward launches (training mode: bounds + STE mask recorded)
+            S("down_proj pair fwd: W4 [4096,11008] + A8 [2048,11008]", "utils_quant.py:195-201,:244-248 via modeling_llama_quant.py:235",
+              self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I),
+            S("A8 [2048,11008] fwd (down_proj input alone)", "utils_quant.py:244-248", self.single_fwd(T, I, 8, "a"), T * I, True, T * I),
+            S("A8 [2048,4096] fwd (shared q/k/v or gate/up input)", "modeling_llama_quant.py:313,317,318,:235", self.single_fwd(T, H, 8, "a"), T * H, True, T * H),
+            S("KV4 [2048,4096] fwd (one of K, V)", "modeling_llama_quant.py:320-327", self.single_fwd(T, H, 4, "a"), T * H, True, T * H),
+            S("quantize_kv pair fwd: K4 + V4 [2048,4096] x2", "modeling_llama_quant.py:320-327 (one launch)", self.pair_fwd(T, "a", 4, T, "a", 4, H),
+              2 * T * H, True, 2 * T * H),
+            S("quantize_kv pair fwd under autocast: fp32 results", "modeling_llama_quant.py:320-327 under kd_trainer.py:106 autocast",
+              self.pair_fwd(T, "a", 4, T, "a", 4, H, autocast=2), 2 * T * H, True, 2 * T * H, bpe_in=2, bpe_out=4),
+            S("q_proj pair fwd: W4 [4096,4096] + A8 [2048,4096]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H),
+            S("W4 [11008,4096] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True),
+            S("q/k/v group fwd in ONE launch: W4 [4096,4096] x3 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:313,317,318 (sibling group)",
+              self.group_launch(qkv, H), (3 * H + T) * H, True, T * H),
+            S("gate/up group fwd in ONE launch: W4 [11008,4096] x2 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:235 (sibling group)",
+              self.group_launch(gu, H), (2 * I + T) * H, True, T * H),
+            # backward launches (their forwards above have filled bounds + masks of the same buffers)
+            S("down_proj pair bwd (weight gradient in place: product default)", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I, inplace0=True),
+              T * I, False, T * I),
+            S("down_proj pair bwd, both gradients to fresh tensors", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I),
+            S("q/k/v group bwd in ONE launch (weight gradients in place)", "utils_quant.py:77-87 x4", self.group_launch(qkv, H, backward=True, inplace=(0, 2, 3)),
+              T * H, False, T * H),
+            S("A8 [2048,4096] bwd", "utils_quant.py:77-87", self.single_bwd(T, H, "a"), T * H, False, T * H),
+            S("quantize_kv pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(T, "a", T, "a", H), 2 * T * H, False, 2 * T * H),
+            S("quantize_kv pair bwd under autocast: fp32 grads in, bf16 out", "utils_quant.py:77-87 x2 + the engine's cast",
+              self.pair_bwd(T, "a", T, "a", H, wide=True), 2 * T * H, False, 2 * T * H, bpe_in=4, bpe_out=2)]
+
+    def entries_compact(self, iters, tag):
+        return time_specs(self.torch, self.specs_compact(tag), iters)
 
     def entries(self, iters):
-        """one roofline entry per launch kind of the layer (name, what it is at the reference call site)"""
-        T, H, I = self.tokens, self.hidden, self.inter
-        torch = self.torch
-        out = []
+        return time_specs(self.torch, self.specs(), iters)
 
-        def add(name, site, fn_sets, elems, fwd, extra_mask_elems=0, bpe_in=2, bpe_out=2):
-            fn, sets = fn_sets
-            t = time_launches(torch, fn, iters, sets)
-            moved = elems * (bpe_in + bpe_out) + extra_mask_elems // 8
-            algo = elems * (FWD_BYTES_PER_ELEM if fwd else BWD_BYTES_PER_ELEM) if (bpe_in, bpe_out) == (2, 2) else moved
-            e = roofline_entry(name, algo, t, moved_bytes=moved)
-            e["reference_call_site"] = site
-            out.append(e)
 
-        # forward launches (training mode: bounds + STE mask recorded)
-        add("down_proj pair fwd: W4 [4096,11008] + A8 [2048,11008]", "utils_quant.py:195-201,:244-248 via modeling_llama_quant.py:235",
-            self.pair_fwd(H, "w", 4, T, "a", 8, I), (H + T) * I, True, T * I)
-        add("A8 [2048,11008] fwd (down_proj input alone)", "utils_quant.py:244-248", self.single_fwd(T, I, 8, "a"), T * I, True, T * I)
-        add("A8 [2048,4096] fwd (shared q/k/v or gate/up input)", "modeling_llama_quant.py:313,317,318,:235", self.single_fwd(T, H, 8, "a"), T * H, True, T * H)
-        add("KV4 [2048,4096] fwd (one of K, V)", "modeling_llama_quant.py:320-327", self.single_fwd(T, H, 4, "a"), T * H, True, T * H)
-        add("quantize_kv pair fwd: K4 + V4 [2048,4096] x2", "modeling_llama_quant.py:320-327 (one launch)", self.pair_fwd(T, "a", 4, T, "a", 4, H),
-            2 * T * H, True, 2 * T * H)
-        add("quantize_kv pair fwd under autocast: fp32 results", "modeling_llama_quant.py:320-327 under kd_trainer.py:106 autocast",
-            self.pair_fwd(T, "a", 4, T, "a", 4, H, autocast=2), 2 * T * H, True, 2 * T * H, bpe_in=2, bpe_out=4)
-        add("q_proj pair fwd: W4 [4096,4096] + A8 [2048,4096]", "modeling_llama_quant.py:313", self.pair_fwd(H, "w", 4, T, "a", 8, H), (H + T) * H, True, T * H)
-        add("W4 [11008,4096] fwd (gate/up weight)", "utils_quant.py:195-201", self.single_fwd(I, H, 4, "w"), I * H, True)
-        qkv = [(H, "w", 4), (T, "a", 8), (H, "w", 4), (H, "w", 4)]
-        add("q/k/v group fwd in ONE launch: W4 [4096,4096] x3 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:313,317,318 (sibling group)",
-            self.group_launch(qkv, H), (3 * H + T) * H, True, T * H)
-        gu = [(I, "w", 4), (T, "a", 8), (I, "w", 4)]
-        add("gate/up group fwd in ONE launch: W4 [11008,4096] x2 + their shared A8 input [2048,4096]", "modeling_llama_quant.py:235 (sibling group)",
-            self.group_launch(gu, H), (2 * I + T) * H, True, T * H)
-        # backward launches (their forwards above have filled bounds + masks of the same buffers)
-        add("down_proj pair bwd (weight gradient in place: product default)", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I, inplace0=True),
-            T * I, False, T * I)
-        add("down_proj pair bwd, both gradients to fresh tensors", "utils_quant.py:77-87 x2", self.pair_bwd(H, "w", T, "a", I), (H + T) * I, False, T * I)
-        add("q/k/v group bwd in ONE launch (weight gradients in place)", "utils_quant.py:77-87 x4", self.group_launch(qkv, H, backward=True, inplace=(0, 2, 3)),
-            T * H, False, T * H)
-        add("A8 [2048,4096] bwd", "utils_quant.py:77-87", self.single_bwd(T, H, "a"), T * H, False, T * H)
-        add("quantize_kv pair bwd", "utils_quant.py:77-87 x2", self.pair_bwd(T, "a", T, "a", H), 2 * T * H, False, 2 * T * H)
-        add("quantize_kv pair bwd under autocast: fp32 grads in, bf16 out", "utils_quant.py:77-87 x2 + the engine's cast",
-            self.pair_bwd(T, "a", T, "a", H, wide=True), 2 * T * H, False, 2 * T * H, bpe_in=4, bpe_out=2)
-        return out
+def time_specs(torch, specs, iters, traffic=None, traffic_source=None):
+    """roofline entries of a list of launch specs (ModelShapes._spec / export_specs / lowbit_asym_specs)"""
+    out = []
+    for sp in specs:
+        t = time_launches(torch, sp["fn"], iters, sp["sets"])
+        e = roofline_entry(sp["name"], sp["algo"], t, (traffic or {}).get(sp["name"]), moved_bytes=sp["moved"], traffic_source=traffic_source)
+        if sp.get("site"):
+            e["reference_call_site"] = sp["site"]
+        out.append(e)
+    return out
 
 
 def baseline_metric_name():
@@ -446,14 +467,15 @@ def roofline_entry(name, algorithmic_bytes, timing, traffic=None, moved_bytes=No
     return e
 
 
-def load_traffic():
-    """HBM bytes per launch from committed rocprofv3 --pmc runs (profiles/traffic.json), if present -- NOT measured in this
+def load_traffic(name="traffic.json"):
+    """HBM bytes per launch from committed rocprofv3 --pmc runs (profiles/traffic.json for the step's kernels,
+    profiles/traffic_model_shapes.json for `--model-shapes` entries, keyed by entry name), if present -- NOT measured in this
     run (PMC collection needs the profiler around the process); the JSON line says so in `traffic_source`."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         try:
             t = json.load(open(p))
-            src = t.pop("_source", None) or ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier bench.py run, "
+            src = t.pop("_source", None) or (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier bench.py run, "
                                              "file mtime " + time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(p))) + "; not measured in this run)")
             return t, src
         except Exception:
@@ -649,6 +671,10 @@ def parse_args(argv=None):
     ap.add_argument("--core-extras", action="store_true",
                     help="per-kernel entries of the step's own kernels only (no model shapes / export / fused GEMM / eager / CPU): what "
                          "tools/profile_bench.sh runs under rocprofv3, so that every fq:: kernel in the trace has ONE launch shape per role")
+    ap.add_argument("--model-shapes", action="store_true",
+                    help="profiling mode: one fq:: launch shape per role (layer launches, export, W1/W2 one-launch, Asym A8), fixed order "
+                         "and call count, manifest on stdout -- what tools/profile_bench.sh runs under rocprofv3 for per-entry PMC traffic")
+    ap.add_argument("--no-sidecar", action="store_true", help="do not write bench_extras.json")
     ap.add_argument("--stub", action="store_true",
                     help="harness self-test: the step is a short sleep, no GPU is touched, the process group is gloo. "
                          "The JSON line says data='stub'; it is never a measurement.")
@@ -777,7 +803,7 @@ def run_stub(args, world, rank, dist, info):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(compact_headline(out), flush=True)
     return 0
 
 
@@ -797,16 +823,22 @@ def main(argv=None):
     ensure_built(local_rank, dist)
     wl = Workload(device)
     wl.prime_bounds()
+    if args.model_shapes:
+        return run_model_shapes(args, wl, rank, dist)
     seconds = timed_region(wl.step, args.steps, args.warmup, torch.cuda.synchronize, dist)
+    # the like-for-like step beside it (both gradients written to fresh tensors), same K / W / barrier / max-over-ranks protocol
+    seconds_oop = timed_region(wl.step_out_of_place, args.steps, args.warmup, torch.cuda.synchronize, dist)
     elems_step = 2 * wl.n
     value = aggregate_value(elems_step, args.steps, world, seconds)
     ms_step = seconds / args.steps * 1e3
+    ms_step_oop = seconds_oop / args.steps * 1e3
     clip_frac = wl.clippable_fraction()
     mask_bytes_a = int(wl.n * clip_frac) // 8          # 1 bit/element for the A8 tensor's clippable rows; the W4 tensor has none
     algo_bytes_step = elems_step * (FWD_BYTES_PER_ELEM + BWD_BYTES_PER_ELEM)
     # bytes the step's two launches move: forward 4 B/elem (+ mask bits); backward 4 B/elem for the A8 tensor (+ mask bits) and
     # NOTHING for the W4 tensor, whose gradient is handed on by reference (in place, no row can clip)
     moved_bytes_step = elems_step * FWD_BYTES_PER_ELEM + wl.n * BWD_MASK_BYTES_PER_ELEM + 2 * mask_bytes_a
+    moved_bytes_step_oop = moved_bytes_step + wl.n * BWD_MASK_BYTES_PER_ELEM
 
     out = {
         "metric": baseline_metric_name(),
@@ -821,10 +853,15 @@ def main(argv=None):
                                "is masked in place (gx == g: rows that cannot clip -- all of a weight's -- are not touched), the "
                                "activation's is written to a fresh tensor",
                    "launches_per_step": "2 (weight + input of a QuantizeLinear share one forward and one backward launch)"},
+        # the like-for-like figure: the same step with BOTH gradients written to fresh tensors (the reference's grad_output.clone(),
+        # utils_quant.py:83-87; what SymQuantizer.apply does for every caller-visible gradient, and what round 1 measured)
+        "value_out_of_place": round(aggregate_value(elems_step, args.steps, world, seconds_oop), 2),
+        "ms_per_step_out_of_place": round(ms_step_oop, 4),
+        # elements whose gradient the timed backward reads + writes: the A8 tensor's (the W4 tensor's gradient is handed on untouched)
+        "backward_elements_touched": wl.n, "backward_elements_touched_out_of_place": 2 * wl.n,
         "hbm_gbs_moved": round(moved_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
-        "hbm_gbs_algorithmic": round(algo_bytes_step / (ms_step * 1e-3) / 1e9 * world, 1),
-        "hbm_gbs_note": "moved = bytes the step's two launches move (fwd 4 + bwd 4 B/elem + mask bits): a real byte rate; algorithmic = "
-                        "SURVEY §8d's 10 B/elem reference-dataflow accounting / step time (the mask backward never re-reads x)",
+        "hbm_gbs_moved_out_of_place": round(moved_bytes_step_oop / (ms_step_oop * 1e-3) / 1e9 * world, 1),
+        "hbm_gbs_note": "bytes the step's two launches move (fwd 4 + bwd 4 B/elem + mask bits) / ms_per_step: a real byte rate",
     }
     out.update(info)
 
@@ -870,8 +907,8 @@ def main(argv=None):
                                                            moved_bytes=bwd_w + bwd_a, traffic_source=tsrc)]
         tw = (0.0, [0.0, 0.0, 0.0]) if args.core_extras else wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it)
         out["ste_bwd_w4_in_place"] = {"us_per_launch": round(tw[0] * 1e3, 2), "us_p10_p50_p90": [round(v * 1e3, 2) for v in tw[1]],
-                                      "what": "fq_ste_bwd_mask with gx == g on the W4 tensor: every row's bounds prove nothing clips, the kernel exits "
-                                              "before any vector memory operation (launch + 8 B per row)"}
+                                      "what": "fq_ste_bwd_mask with gx == g on the W4 tensor: every row's bounds prove nothing clips; one block per 256 "
+                                              "rows reads their bounds (8 B per row) and exits"}
         ac = {
             "sym_fwd_w4_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "w", False), nb * FWD_BYTES_PER_ELEM),
             "sym_fwd_a8_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "a", False), nb * FWD_BYTES_PER_ELEM),
@@ -890,13 +927,16 @@ def main(argv=None):
             if k in fwp:
                 out["roofline"][k] = fwp[k]
         tot_us = sum(e["us_per_launch"] for e in out["kernels_step"])
+        tot_us_oop = out["kernels_step"][0]["us_per_launch"] + out["kernels_step_out_of_place"][0]["us_per_launch"]
+        # the credit figure for the whole step: BYTES MOVED / time (never the 10 B/elem accounting, which can exceed the peak)
         out["roofline_step"] = {"bound": "hbm", "achieved": round(moved_bytes_step / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(moved_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                "bytes_moved_per_step": moved_bytes_step,
-                                "achieved_algorithmic": round(algo_bytes_step / (tot_us * 1e-6) / 1e9, 1),
-                                "frac_algorithmic": round(algo_bytes_step / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                "frac_algorithmic_note": "10 B/elem reference-dataflow equivalent (SURVEY §8d), not a byte rate",
-                                "what": "both launches of one step: bytes moved / sum of launch times"}
+                                "bytes_moved_per_step": moved_bytes_step, "us_per_step_launches": round(tot_us, 2),
+                                "out_of_place": {"bytes_moved_per_step": moved_bytes_step_oop, "us_per_step_launches": round(tot_us_oop, 2),
+                                                 "achieved": round(moved_bytes_step_oop / (tot_us_oop * 1e-6) / 1e9, 1),
+                                                 "frac": round(moved_bytes_step_oop / (tot_us_oop * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                                "reference_dataflow_bytes_per_step": algo_bytes_step,
+                                "what": "both launches of one step: bytes moved / sum of launch times (out_of_place: both gradients written)"}
         out["unpaired_step"] = {"ms_per_step": None if args.core_extras else round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
                                 "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2; weight gradient in place)"}
         if not args.core_extras:
@@ -909,13 +949,14 @@ def main(argv=None):
                                  "us_p10_p50_p90": [round(v * 1e3, 2) for v in cpct]}
         # the launches of one LLaMA-7B layer at their real shapes
         if not args.core_extras:
-            out["kernels_model_shapes"] = ModelShapes(wl).entries(it)
+            mtraffic, msrc = load_traffic("traffic_model_shapes.json")
+            out["kernels_model_shapes"] = time_specs(torch, ModelShapes(wl).specs(), it, mtraffic, msrc)
             out["kernels_model_shapes_13b"] = ModelShapes(wl, hidden=5120, inter=13824).entries_compact(max(10, it // 2), "13B")
-        for hook in ([] if args.core_extras else EXTRA_ENTRIES):   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
-            try:
-                out.update(hook(wl, it))
-            except Exception as e:  # noqa: BLE001  -- an extra entry must never lose the headline line
-                out.setdefault("extras_failed", []).append(f"{getattr(hook, '__name__', hook)}: {e!r}")
+            for hook in EXTRA_ENTRIES:   # further kernel families register here (export, fused QuantizeLinear, W1/W2, Asym)
+                try:
+                    out.update(hook(wl, it, mtraffic, msrc))
+                except Exception as e:  # noqa: BLE001  -- an extra entry must never lose the headline line
+                    out.setdefault("extras_failed", []).append(f"{getattr(hook, '__name__', hook)}: {e!r}")
         if world == 1 and not args.core_extras:
             out["gpu_eager"] = gpu_eager(wl)
             out["gpu_eager_autocast"] = gpu_eager(wl, autocast=True)
@@ -927,11 +968,106 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        emit(out, args)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------
+# output: the LAST stdout line is a compact headline the driver can parse from an 8 KB tail; everything else goes before it
+# ----------------------------------------------------------------------------------------------
+HEADLINE_MAX_BYTES = 4096
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "kernel", "algorithmic_bytes_per_launch", "traffic_source")
+_HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "value_out_of_place", "ms_per_step_out_of_place", "backward_elements_touched", "hbm_gbs_moved", "ranks_seen", "dist_backend",
+              "dist_backend_fallback", "ranks_share_devices", "stub", "extras_failed")
+
+
+def _clip(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "…"
+
+
+def compact_headline(out, extras_file=None):
+    """The one line the driver parses: the contract's keys + roofline + roofline_step + cpu_baseline, hard-capped at
+    HEADLINE_MAX_BYTES (the driver keeps an 8 KB stdout tail; round 2's 27 KB line was cut and never parsed)."""
+    h = {k: out[k] for k in _HEAD_KEYS if k in out}
+    cfg = out.get("config", {})
+    h["config"] = {"workload": _clip(cfg.get("workload", ""), 170), "parallelism": cfg.get("parallelism"),
+                   "backward": "weight grad in place, activation grad copied (product default); value_out_of_place = both copied"}
+    if "elements_per_step" in cfg:
+        h["config"]["elements_per_step"] = cfg["elements_per_step"]
+    r = out.get("roofline")
+    if r:
+        h["roofline"] = {k: (_clip(r[k], 150) if k in ("kernel", "traffic_source") else r[k]) for k in _ROOFLINE_KEYS if k in r}
+    rs = out.get("roofline_step")
+    if rs:
+        h["roofline_step"] = {k: rs[k] for k in ("bound", "achieved", "peak", "unit", "frac", "bytes_moved_per_step", "us_per_step_launches", "out_of_place") if k in rs}
+    c = out.get("cpu_baseline")
+    if c:
+        h["cpu_baseline"] = {k: (_clip(c[k], 200) if k == "sample" else c[k])
+                             for k in ("value", "unit", "cores", "kind", "sample", "host_cpu", "seconds_best", "parity_gate") if k in c}
+    ge = out.get("gpu_eager")
+    if ge:
+        h["gpu_eager_gelem_s"] = ge.get("value")
+        if ge.get("value"):
+            h["speedup_vs_gpu_eager"] = round(out["value"] / ge["value"], 2)
+    if extras_file:
+        h["extras"] = extras_file
+    line = json.dumps(h)
+    if len(line.encode()) >= HEADLINE_MAX_BYTES:   # cannot happen with the clips above; if it ever does, shed the optional parts, never the contract
+        for k in ("gpu_eager_gelem_s", "speedup_vs_gpu_eager", "extras", "roofline_step", "cpu_baseline"):
+            h.pop(k, None)
+            line = json.dumps(h)
+            if len(line.encode()) < HEADLINE_MAX_BYTES:
+                break
+    return line
+
+
+def emit(out, args):
+    """full record -> bench_extras.json (next to bench.py, and gpurun_out/ when that exists) + one earlier stdout line per extras
+    family; then the compact headline as the LAST stdout line."""
+    head_keys = set(_HEAD_KEYS) | {"config", "roofline", "roofline_step", "cpu_baseline", "hbm_gbs_note"}
+    extras_file = None
+    if not getattr(args, "no_sidecar", False):
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            try:
+                if os.path.isdir(d):
+                    with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                        json.dump(out, f, indent=1)
+                    extras_file = extras_file or "bench_extras.json (next to bench.py; the same families are the stdout lines above this one)"
+            except OSError:
+                pass
+    for k, v in out.items():
+        if k not in head_keys:
+            print(json.dumps({"bench_extras": k, "data": v}), flush=True)
+    print(compact_headline(out, extras_file), flush=True)
+
+
+def run_model_shapes(args, wl, rank, dist):
+    """Profiling mode (tools/profile_bench.sh): every launch kind of the layer, the export kernels, the one-launch W1/W2 kernel and
+    Asym A8, ONE fq:: kernel per call, in a fixed order, each for the same number of calls -- so a rocprofv3 kernel trace / PMC pass
+    of this command splits into one segment per entry by counting fq:: dispatches (tools/summarize_profile.py).  Prints a manifest
+    (entry -> calls, bytes) with the HIP-event timings; it is not the headline measurement."""
+    torch = wl.torch
+    iters = max(10, min(args.steps, 50))
+    specs = ModelShapes(wl).specs() + export_specs(wl) + lowbit_asym_specs(wl, fused_only=True)
+    mtraffic, msrc = load_traffic("traffic_model_shapes.json")
+    entries = time_specs(torch, specs, iters, mtraffic, msrc)
+    calls = 3 + 2 * iters   # time_launches: 3 warm-up + iters back-to-back + iters individually bracketed
+    out = {"mode": "model-shapes", "fq_launches_per_entry": calls, "prologue_fq_launches": 2 * wl.nsets,
+           "entries": entries, "order": [sp["name"] for sp in specs]}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        for d in (os.path.join(ROOT, "gpurun_out"),):
+            if os.path.isdir(d):
+                json.dump(out, open(os.path.join(d, "bench_model_shapes.json"), "w"), indent=1)
         print(json.dumps(out), flush=True)
     return 0
 
 
-def export_entries(wl, iters):
+def export_specs(wl):
     """packed-bin export and the scale pre-pass on the metric tensor (bf16 [4096,11008])"""
     torch, L, lib_, st = wl.torch, wl.L, wl._lib, wl.stream
     rows, cols, n = wl.rows, wl.cols, wl.n
@@ -953,17 +1089,22 @@ def export_entries(wl, iters):
     def scales(key, bits):
         return lambda s: chk(L.fq_sym_row_scales(s[key].data_ptr(), s["scales"].data_ptr(), rows, cols, bits, code, 0, 0, -2.0, 2.0, None, None, 0, st))
 
+    site = "utils_quant.py:71-72 (the bins `torch.round(input * s)`)"
     ks = [("sym_export_w4_int4", exp("w", 4, lib_.BINS_INT4), n * 2 + n // 2),
           ("sym_export_w8_int8", exp("w", 8, lib_.BINS_INT8), n * 3),
           ("sym_export_a8_int8", exp("a", 8, lib_.BINS_INT8), n * 3),
           ("sym_row_scales_w4 (pre-pass: read only)", scales("w", 4), n * 2)]
-    return {"kernels_export": [roofline_entry(k, b, wl.time_kernel(fn, iters)) for k, fn, b in ks]}
+    return [dict(name=k, site=site, fn=fn, sets=wl.sets, algo=b, moved=b) for k, fn, b in ks]
+
+
+def export_entries(wl, iters, traffic=None, tsrc=None):
+    return {"kernels_export": time_specs(wl.torch, export_specs(wl), iters, traffic, tsrc)}
 
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def qlinear_entries(wl, iters):
+def qlinear_entries(wl, iters, traffic=None, tsrc=None):
     """SURVEY §8 f4a on its named shape: QuantizeLinear's no-grad forward for down_proj, x[2048,11008] . W[4096,11008]^T, W4 A8 --
     the unfused product path (one fq pair launch + F.linear / hipBLASLt) beside fq_qlinear_fwd (fake-quant applied in the
     GEMM's operand staging).  Roofline of the fused kernel: MFMA (dense bf16 peak)."""
@@ -1017,9 +1158,10 @@ def qlinear_entries(wl, iters):
                                              "x: out/128 = 32x) and does not hide under the MFMAs; see DESIGN.md §10"}}
 
 
-def lowbit_asym_entries(wl, iters):
-    """the 1-/2-bit weight branches on [4096,11008] bf16 (utils_quant.py:202-242) -- the default
-    (ATen abs + mean, then fq_w12_fwd: 3 launches) and the opt-in one-launch kernel -- and AsymQuantizer A8 on [2048,11008]."""
+def lowbit_asym_specs(wl, fused_only=False):
+    """The 1-/2-bit weight branches on [4096,11008] bf16 (utils_quant.py:202-242) -- the default (ATen abs + mean, then
+    fq_w12_fwd: 3 launches) and the opt-in one-launch kernel -- and AsymQuantizer A8 on [2048,11008].
+    fused_only: leave out the entries that launch ATen kernels too (profiling mode: one fq:: launch per call)."""
     torch, L, lib_, st = wl.torch, wl.L, wl._lib, wl.stream
     rows, cols, n = wl.rows, wl.cols, wl.n
     code = lib_.DTYPE_BF16
@@ -1042,6 +1184,7 @@ def lowbit_asym_entries(wl, iters):
         return lambda s: chk(L.fq_w12_fwd_rows(s["w"].data_ptr(), s["yw"].data_ptr(), s["sc16"].data_ptr(), rows, cols, bits, code, 0, st))
 
     t2 = 2048
+
     def asym(s):
         chk(L.fq_asym_fwd_train(s["a"].data_ptr(), s["ya"].data_ptr(), t2, cols, 8, code, 0, -2.0, 2.0, s["ba"].data_ptr(), s["ma"].data_ptr(), wl.mask_bytes, st))
 
@@ -1050,11 +1193,14 @@ def lowbit_asym_entries(wl, iters):
           ("w12 1-bit one launch (opt-in, in-kernel row mean)", w12_fused(1), n * 4, n * 4),
           ("w12 2-bit one launch (opt-in, in-kernel row mean)", w12_fused(2), n * 4, n * 4),
           ("asym_fwd_a8 bf16 [2048,11008] (training mode)", asym, t2 * cols * 4, t2 * cols * 4 + t2 * cols // 8)]
-    out = []
-    for k, fn, algo, moved in ks:
-        e = roofline_entry(k, algo, wl.time_kernel(fn, iters), moved_bytes=moved)
-        out.append(e)
-    return {"kernels_lowbit_asym": out}
+    if fused_only:
+        ks = ks[2:]
+    site = "utils_quant.py:202-242 (W1/W2), :110-149 (Asym)"
+    return [dict(name=k, site=site, fn=fn, sets=wl.sets, algo=algo, moved=moved) for k, fn, algo, moved in ks]
+
+
+def lowbit_asym_entries(wl, iters, traffic=None, tsrc=None):
+    return {"kernels_lowbit_asym": time_specs(wl.torch, lowbit_asym_specs(wl), iters, traffic, tsrc)}
 
 
 EXTRA_ENTRIES = [export_entries, qlinear_entries, lowbit_asym_entries]

@@ -121,3 +121,64 @@ def test_a_failing_rank_fails_the_job(tmp_path):
 def test_one_gpu_default_has_no_process_group_keys():
     p, out = _run_bench(["--stub", "--steps", "2", "--warmup", "0"])
     assert p.returncode == 0 and out["n_gpus"] == 1 and out["ranks_seen"] == 1 and "dist_backend" not in out
+
+
+# ---- the line the driver parses (round 2's single 27 KB line was cut by the driver's 8 KB tail) ----
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "roofline_step", "cpu_baseline", "ranks_seen")
+
+
+def _full_record():
+    """a realistic full record: round 2's 27 KB line, plus the round-3 keys"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    full.update({"value_out_of_place": 755.0, "ms_per_step_out_of_place": 0.1194, "backward_elements_touched": 45088768})
+    full["roofline_step"]["us_per_step_launches"] = 93.0
+    full["roofline_step"]["out_of_place"] = {"bytes_moved_per_step": 732692480, "us_per_step_launches": 119.2, "achieved": 6146.7, "frac": 0.7683}
+    return full
+
+
+def test_headline_is_compact_and_complete():
+    full = _full_record()
+    assert len(json.dumps(full)) > 20000                       # the record itself is far beyond what the driver's tail keeps
+    line = bench.compact_headline(full, "bench_extras.json")
+    assert len(line.encode()) < bench.HEADLINE_MAX_BYTES == 4096
+    h = json.loads(line)
+    for k in HEADLINE_KEYS + ("value_out_of_place", "backward_elements_touched"):
+        assert k in h, k
+    assert len(json.dumps(h["config"])) <= 400 and "model" not in h["config"] and h["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "kernel"):
+        assert k in h["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample", "parity_gate"):
+        assert k in h["cpu_baseline"], k
+    assert h["roofline_step"]["frac"] <= 1.0 and h["roofline_step"]["out_of_place"]["frac"] <= 1.0
+    assert "hbm_gbs_algorithmic" not in h                      # a GB/s above the 8 TB/s peak has no place in the headline
+    assert h["value"] == full["value"] and h["ms_per_step"] == full["ms_per_step"] and h["roofline"]["frac"] == full["roofline"]["frac"]
+
+
+def test_headline_stays_compact_whatever_the_extras_grow_to():
+    full = _full_record()
+    for i in range(60):                                        # a future round registers 60 more kernel families
+        full[f"kernels_future_{i}"] = [dict(full["kernels"][0]) for _ in range(10)]
+    full["config"]["workload"] = "W" * 5000
+    full["roofline"]["kernel"] = "K" * 5000
+    full["cpu_baseline"]["sample"] = "S" * 5000
+    assert len(bench.compact_headline(full, "x").encode()) < 4096
+
+
+def test_emit_prints_extras_first_and_the_headline_last(capsys):
+    import argparse
+    full = _full_record()
+    bench.emit(full, argparse.Namespace(no_sidecar=True))
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) > 5 and all(json.loads(ln).get("bench_extras") for ln in lines[:-1])
+    fams = {json.loads(ln)["bench_extras"] for ln in lines[:-1]}
+    assert {"kernels", "kernels_step", "kernels_model_shapes", "kernels_export", "gpu_eager"} <= fams
+    last = json.loads(lines[-1])
+    assert len(lines[-1].encode()) < 4096 and "bench_extras" not in last and last["value"] == full["value"]
+
+
+def test_stub_line_is_compact_too():
+    p, out = _run_bench(["--stub", "--steps", "2", "--warmup", "0"])
+    assert p.returncode == 0
+    last = p.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 4096 and json.loads(last)["data"] == "stub"

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FQ_ABI_VERSION 2 /* 2: + multi-tensor launches, export, row scales, fq_qlinear_fwd, fq_w12_fwd_rows */
+#define FQ_ABI_VERSION 3 /* 2: + multi-tensor launches, export, row scales, fq_qlinear_fwd, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap */
 
 /* element types */
 #define FQ_DTYPE_F32 0
@@ -125,8 +125,12 @@ int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
  * instead of 4 + 6.  Results are bit-identical to fq_*_fwd + fq_ste_bwd.  The autograd Functions need not
  * keep `input` alive for the backward in this mode (the reference saves it, utils_quant.py:45).
  *
- * fq_ste_mask_bytes  size of the mask buffer for this shape; 0 if the shape is not served (rows that do
- *                    not fit the register-resident kernels, or cols not a multiple of a 16-byte vector):
+ * Mask layout (ABI 3; one layout for every producer and consumer): a plain bitmap per row.  Row r starts at byte
+ *                    r * 8 * ceil(cols / 64); bit (j % 8) of its byte (j / 8) is the flag of element j of the row,
+ *                    1 = the backward zeroes that gradient (x >= hi || x <= lo; a NaN x has flag 0).  Rows whose recorded
+ *                    bounds lie strictly inside (lo, hi) are NOT written (the backward decides from the bounds first).
+ * fq_ste_mask_bytes  size of the mask buffer for this shape = rows * 8 * ceil(cols / 64); 0 if the shape is not served
+ *                    (rows that do not fit the register-resident kernels, or cols not a multiple of a 16-byte vector):
  *                    use fq_*_fwd + fq_ste_bwd[_rows] then.  Contents need no initialisation.
  * fq_*_fwd_train     lo/hi = the STE clip (clip_val[0], clip_val[1]); row_bounds_out and mask_out required.
  *                    Returns FQ_ERR_UNSUPPORTED if x/y are not 16-byte aligned.
@@ -135,7 +139,9 @@ int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
  *                    IN PLACE: gx may be the same pointer as g (also per tensor in fq_ste_bwd_mask_pair / _multi).  The
  *                    gradient is then masked where it stands, and a row whose bounds prove that nothing is clipped is not
  *                    touched at all: for a weight (whose rows practically never reach the clip) the STE backward moves no
- *                    bytes -- the reference's `grad_output.clone()` (:84) exists only to be mutated by :85-86.
+ *                    bytes -- the reference's `grad_output.clone()` (:84) exists only to be mutated by :85-86.  An in-place
+ *                    tensor gets one workgroup per 256 rows (it reads their bounds and walks the clippable ones), so it is
+ *                    meant for tensors whose rows rarely clip; an activation's gradient belongs in a copying call.
  */
 size_t fq_ste_mask_bytes(int64_t rows, int64_t cols, int dtype);
 int fq_sym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, float lo, float hi,
@@ -159,9 +165,9 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
  *   row_bounds_out / mask_out  optional training-mode outputs, as in fq_sym_fwd_train (mask_out needs row_bounds_out).
  *             wide_out = 0: the backward is fq_ste_bwd_mask / fq_ste_bwd on the input dtype.
  *             wide_out = 1: the gradient of the fp32 result is fp32 and the autograd engine casts it to the input dtype
- *             (grad of a bf16 leaf is bf16); fq_ste_bwd_mask_wide does cast + masking in one pass and is the ONLY
- *             consumer of a mask written with wide_out = 1 (its bit layout follows the fp32 stream: 4 elements per
- *             lane instead of 8; same buffer size).  Without a mask: cast grad_output, then fq_ste_bwd_rows / fq_ste_bwd.
+ *             (grad of a bf16 leaf is bf16); fq_ste_bwd_mask_wide does cast + masking in one pass (the mask is the same
+ *             row bitmap whatever wide_out is, so fq_ste_bwd_mask on an already cast gradient serves it too).  Without a
+ *             mask: cast grad_output, then fq_ste_bwd_rows / fq_ste_bwd.
  *   workspace  fq_rowwise_workspace_bytes(rows, cols, dtype) bytes (only rows longer than 32768 elements use it)
  * Returns FQ_ERR_UNSUPPORTED when a mask is requested for a shape fq_ste_mask_bytes rejects or for misaligned rows.
  */

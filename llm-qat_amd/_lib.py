@@ -8,7 +8,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libllmqat_fakequant.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 SEM_CPU_EAGER, SEM_DEVICE_EAGER = 0, 1

@@ -24,18 +24,20 @@ def up_to_date():
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
 
-def build_extension(force=False, verbose=False):
-    if not force and up_to_date():
+def build_extension(force=False, verbose=False, extra_flags=(), out=None):
+    """extra_flags / out: A/B builds of kernel variants for tools/ab_bench.sh (e.g. -DFQ_MASK_FETCH_BYTES=1 -> another .so);
+    the product build takes neither."""
+    if out is None and not force and up_to_date():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in SOURCES:  # one translation unit per element type: compile them side by side
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", "-o", obj, src]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), obj, cmd))
@@ -44,12 +46,14 @@ def build_extension(force=False, verbose=False):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
         objs.append(obj)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    print(build_extension(force="--force" in sys.argv, verbose=True))
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[len("--out="):] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build_extension(force="--force" in sys.argv, verbose=True, extra_flags=extra, out=outs[0] if outs else None))

@@ -49,7 +49,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, sem);
-    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, 0, {}};
+    RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, 0u, rows, 0, {}};
     if (mk) {
         if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
         const int64_t mrw = mask_row_words(cols, esize_of(dtype));
@@ -59,6 +59,7 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
         a.mask_row_words = mrw;
         a.lo = host_rb(mk->lo, dtype);
         a.hi = host_rb(mk->hi, dtype);
+        a.clipk = ste_clip_key(a.lo, a.hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
     // reciprocal-multiply instead of IEEE divide (only honoured for bf16).  Sym: valid for every bit width, because
@@ -141,7 +142,7 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     const Consts c = make_consts(bits, dtype, FQ_SEM_DEVICE_EAGER);
-    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, rows, 0, {}};
+    RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, 0u, rows, 0, {}};
     if (mask_out) {
         if (!row_bounds_out) return fail(FQ_ERR_NULL, "a mask needs row_bounds_out too");
         const int64_t mrw = mask_row_words(cols, 2);
@@ -151,6 +152,7 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
         a.mask_row_words = mrw;
         a.lo = host_rb(lo, dtype);
         a.hi = host_rb(hi, dtype);
+        a.clipk = ste_clip_key(a.lo, a.hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
     return dtype == FQ_DTYPE_BF16 ? launch_sym_autocast<BF16>(wide_out != 0, a, workspace, workspace_bytes, st)
@@ -177,7 +179,7 @@ FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dty
     }
     const Consts c0 = make_consts(t[0].bits, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem);
     RowArgs a{t[0].x, t[0].y, nullptr, nullptr, t[0].row_bounds, total, cols, c0.sym, c0.asym, (uint64_t*)t[0].mask, mrw, host_rb(lo, dtype),
-              host_rb(hi, dtype), t[0].rows, n - 1, {}};
+              host_rb(hi, dtype), ste_clip_key(host_rb(lo, dtype), host_rb(hi, dtype), dtype), t[0].rows, n - 1, {}};
     int64_t begin = t[0].rows;
     for (int i = 1; i < n; ++i) {
         a.more[i - 1] = TensorSlot{begin, t[i].x, t[i].y, t[i].row_bounds, (uint64_t*)t[i].mask, make_consts(t[i].bits, dtype, sem).sym.qmax};
@@ -216,25 +218,15 @@ FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, fl
     }
     lo = host_rb(lo, dtype);
     hi = host_rb(hi, dtype);
-    SteMore m{};
-    m.rows0 = t[0].rows;
-    m.n = n - 1;
-    int64_t begin = t[0].rows;
-    for (int i = 1; i < n; ++i) {
-        m.t[i - 1] = SteSlot{begin, t[i].g, t[i].gx, t[i].row_bounds, (const uint64_t*)t[i].mask};
-        begin += t[i].rows;
-    }
+    SteLaunch L{};
+    L.n = n;
+    for (int i = 0; i < n; ++i) L.t[i] = SteSlot{t[i].g, t[i].gx, t[i].row_bounds, (const uint64_t*)t[i].mask, t[i].rows, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-    const SteMore* mp = n > 1 ? &m : nullptr;
-    const float* b0 = t[0].row_bounds;
-    const uint64_t* m0 = (const uint64_t*)t[0].mask;
-    if (wide_grad)
-        return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp)
-                                      : launch_ste_mask_wide<F16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+    if (wide_grad) return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(L, cols, lo, hi, st) : launch_ste_mask_wide<F16>(L, cols, lo, hi, st);
     switch (dtype) {
-        case FQ_DTYPE_F32: return launch_ste_mask<F32>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
-        case FQ_DTYPE_F16: return launch_ste_mask<F16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
-        default: return launch_ste_mask<BF16>(t[0].g, t[0].gx, total, cols, lo, hi, b0, m0, st, mp);
+        case FQ_DTYPE_F32: return launch_ste_mask<F32>(L, cols, lo, hi, st);
+        case FQ_DTYPE_F16: return launch_ste_mask<F16>(L, cols, lo, hi, st);
+        default: return launch_ste_mask<BF16>(L, cols, lo, hi, st);
     }
 }
 
@@ -265,14 +257,8 @@ FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, 
     const int64_t mrw = mask_row_words(cols, esize_of(dtype));
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the STE-mask path (see fq_ste_mask_bytes)");
     if (mask_bytes < (size_t)rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
-    lo = host_rb(lo, dtype);
-    hi = host_rb(hi, dtype);
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case FQ_DTYPE_F32: return launch_ste_mask<F32>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
-        case FQ_DTYPE_F16: return launch_ste_mask<F16>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
-        default: return launch_ste_mask<BF16>(g, gx, rows, cols, lo, hi, row_bounds, (const uint64_t*)mask, st);
-    }
+    const fq_bwd_tensor t{g, gx, rows, row_bounds, mask};
+    return fq_ste_bwd_mask_multi(1, &t, cols, lo, hi, dtype, 0, stream);
 }
 
 FQ_API int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,

@@ -384,8 +384,9 @@ __device__ __forceinline__ uint32_t asym_dword(uint32_t w, const AsymRow& r, con
 // detach trick  weight = q.detach() - w.detach() + w  (two more roundings; gradient is the identity).
 //   1 bit : q = sc * sign(w / sc)                                            sign(NaN) = sign(0) = 0, as torch.sign
 //   2 bit : q = sc * (round(clamp(w / sc, -cv, cv) * 2 - 0.5) + 0.5) / 2     cv = 0.99 (clamp propagates NaN)
-// rsc = 1 / sc and mk = div_exact_ok(sc) are per row: w / sc then costs 3-4 VALU ops instead of the IEEE sequence, same bits
-// (div_exact()'s second precondition, |w| >= 2^-100 or w == 0, is checked per element).
+// w12_elem is the reference chain op for op (any scale: zero, NaN, infinite, subnormal); rsc = 1 / sc and mk = div_exact_ok(sc)
+// are per row: w / sc then costs 3-4 VALU ops instead of the IEEE sequence, same bits (div_exact()'s second precondition,
+// |w| >= 2^-100 or w == 0, is checked per element).  Rows with an ordinary scale take w12_dword below.
 template <int DT, int WBITS> __device__ __forceinline__ float w12_elem(float w, float sc, float cv, float rsc, bool mk) {
     using T = Ty<DT>;
     const bool fast = mk && (__builtin_fabsf(w) >= 0x1p-100f || w == 0.0f) && !(__builtin_fabsf(w) == __builtin_inff());
@@ -404,6 +405,123 @@ template <int DT, int WBITS> __device__ __forceinline__ float w12_elem(float w, 
         q = T::rb(u / 2.0f);
     }
     return T::rb(q - w) + w;  // rounded once more by the store
+}
+
+// The same chain on one dword (two 16-bit elements / one fp32) for a row whose scale is ORDINARY (mk: sc in [2^-60, 2^100],
+// so rsc is normal and nothing below underflows), written on float2 so that the multiplies / adds / explicit fmas become
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, and with the steps that are provably the identity for such a row removed:
+//  * bf16: w / sc == rb(w * rsc) after the rounding to bf16 (numerator and divisor have 8-bit significands: the quotient is
+//    never within 2^-17 of a bf16 rounding midpoint, the reciprocal multiply errs by < 2^-22; DESIGN.md "Numerics", checked
+//    exhaustively in tests/test_oracle_golden.py) wherever the quotient is a NORMAL bf16 value.  Below that the 2-bit chain
+//    does not see the difference (|t| < 2^-26 vanishes in `2 t - 0.5`), the 1-bit chain does (sign(t) = 0 once t rounds to
+//    zero): it sends |w * rsc| < 2^-100 (w != 0) to w12_elem.  fp16 keeps div_exact (always applicable: a non-zero fp16 value
+//    is >= 2^-24); fp32 checks div_exact's precondition per element.
+//  * t is NaN only if w is (sc is finite and positive), and then `+ w` makes the result NaN whatever came before: the clamp
+//    needs no NaN select (v_med3_f32).
+//  * rb(clamp(t, +-cv)) == clamp(t, +-rb(cv)) for a dtype-valued t (rounding is monotone, t is a fixed point): cvr = rb(cv).
+//  * 2 c - 0.5 in one explicit fma (2 c is exact); (r + 0.5) * sc / 2 == fma(r, sc/2, sc/4) rounded once: r * (sc/2) and the sum
+//    are exact reals before the single rounding, and halving commutes with rounding while nothing is subnormal (bf16, fp32:
+//    sc >= 2^-60; fp16 tensors keep the reference's two steps, their sc * u can be subnormal).
+struct W12Row {
+    float sc, rsc, sch, scq, cvr;  // scale, 1 / sc, sc / 2, sc / 4, rb(cv)
+    bool mk;
+};
+template <int DT> __device__ __forceinline__ W12Row w12_row(float sc, float cv) {
+    W12Row r;
+    r.sc = sc;
+    r.rsc = 1.0f / sc;
+    r.sch = 0.5f * sc;
+    r.scq = 0.25f * sc;
+    r.cvr = Ty<DT>::rb(cv);
+    r.mk = div_exact_ok(sc);
+    return r;
+}
+template <int DT> __device__ __forceinline__ f32x2_t rb2(f32x2_t v) {  // round both to the dtype (bf16: one v_cvt_pk_bf16_f32)
+    float f[2] = {v.x, v.y};
+    Ty<DT>::round_dt(f);
+    f32x2_t o;
+    o.x = f[0];
+    o.y = f[1];
+    return o;
+}
+// any scale / any element (the callers branch once per row or vector, wave-uniformly, never per dword)
+template <int DT, int WBITS> __device__ __forceinline__ uint32_t w12_dword_any(uint32_t wbits, const W12Row& r, float cv) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(wbits, f);
+#pragma unroll
+    for (int e = 0; e < T::EPD; ++e) f[e] = w12_elem<DT, WBITS>(f[e], r.sc, cv, r.rsc, r.mk);
+    return T::pack(f);
+}
+// r.mk must hold.  `odd` is set when an element needs the reference chain instead (1-bit bf16: a quotient that may round to
+// zero; fp32: an element outside div_exact's precondition): the caller then redoes the vector with w12_dword_any behind a
+// wave-uniform branch (a per-lane select would make the compiler execute the IEEE divisions for every element).
+template <int DT, int WBITS> __device__ __forceinline__ uint32_t w12_dword(uint32_t wbits, const W12Row& r, bool& odd) {
+    using T = Ty<DT>;
+    float f[T::EPD];
+    T::unpack(wbits, f);
+    if constexpr (T::EPD == 1) {
+        const float w = f[0], aw = __builtin_fabsf(w);
+        odd = odd || !((aw >= 0x1p-100f || w == 0.0f) && !(aw == __builtin_inff()));
+        float t = div_exact(w, r.sc, r.rsc), q;
+        if constexpr (WBITS == 1) q = (t > 0.f) ? r.sc : (t < 0.f) ? -r.sc : 0.f;
+        else q = __builtin_fmaf(__builtin_rintf(__builtin_fmaf(__builtin_amdgcn_fmed3f(t, -r.cvr, r.cvr), 2.0f, -0.5f)), r.sch, r.scq);
+        f[0] = (q - w) + w;
+        return T::pack(f);
+    } else {
+        f32x2_t w2, t;
+        w2.x = f[0];
+        w2.y = f[1];
+        const f32x2_t q0 = w2 * r.rsc;
+        if constexpr (DT == BF16) {
+            t = q0;
+            if constexpr (WBITS == 1)  // sign(t) needs the exact quotient where t may round to zero
+                odd = odd || (__builtin_fabsf(q0.x) < 0x1p-100f && w2.x != 0.0f) || (__builtin_fabsf(q0.y) < 0x1p-100f && w2.y != 0.0f);
+        } else {  // fp16: Markstein-corrected quotient, the division bit for bit
+            const f32x2_t e2 = __builtin_elementwise_fma(-q0, (f32x2_t){r.sc, r.sc}, w2);
+            const f32x2_t c2 = __builtin_elementwise_fma(e2, (f32x2_t){r.rsc, r.rsc}, q0);
+            t.x = (e2.x == 0.0f || __builtin_fabsf(q0.x) == __builtin_inff()) ? q0.x : c2.x;
+            t.y = (e2.y == 0.0f || __builtin_fabsf(q0.y) == __builtin_inff()) ? q0.y : c2.y;
+        }
+        t = rb2<DT>(t);
+        f32x2_t q;
+        if constexpr (WBITS == 1) {
+            q.x = (t.x > 0.f) ? r.sc : (t.x < 0.f) ? -r.sc : 0.f;
+            q.y = (t.y > 0.f) ? r.sc : (t.y < 0.f) ? -r.sc : 0.f;
+        } else {
+            f32x2_t c;
+            c.x = __builtin_amdgcn_fmed3f(t.x, -r.cvr, r.cvr);
+            c.y = __builtin_amdgcn_fmed3f(t.y, -r.cvr, r.cvr);
+            f32x2_t u = rb2<DT>(__builtin_elementwise_fma(c, (f32x2_t){2.0f, 2.0f}, (f32x2_t){-0.5f, -0.5f}));
+            u.x = __builtin_rintf(u.x);
+            u.y = __builtin_rintf(u.y);
+            if constexpr (DT == BF16) {
+                q = rb2<DT>(__builtin_elementwise_fma(u, (f32x2_t){r.sch, r.sch}, (f32x2_t){r.scq, r.scq}));
+            } else {
+                q = rb2<DT>((u + 0.5f) * r.sc);
+                q = rb2<DT>(q * 0.5f);
+            }
+        }
+        const f32x2_t d = rb2<DT>(q - w2) + w2;
+        f[0] = d.x;
+        f[1] = d.y;
+        return T::pack(f);
+    }
+}
+// one 16-byte vector: the fast chain, redone with the reference chain if any lane of the wave met an odd element
+template <int DT, int WBITS> __device__ __forceinline__ uint4 w12_vec(const uint4& in, const W12Row& r, float cv) {
+    const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+    uint32_t o[4];
+    bool odd = false;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = w12_dword<DT, WBITS>(w[d], r, odd);
+    if constexpr (DT == F32 || (DT == BF16 && WBITS == 1)) {
+        if (__builtin_amdgcn_ballot_w64(odd) != 0) {  // wave-uniform, practically never taken
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = w12_dword_any<DT, WBITS>(w[d], r, cv);
+        }
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // min/max/NaN accumulation for Asym on one dword

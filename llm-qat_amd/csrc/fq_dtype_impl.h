@@ -259,42 +259,57 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     return launch_result();
 }
 
-template <int DT>
-int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
-                    hipStream_t st, const SteMore* more) {
+// block layout of a mask-backward launch (grid x): copying slots get one block per row, in-place slots one per STE_THREADS rows;
+// grid y = chunks of a row.  Unused slots: blk_begin = INT64_MAX (ste_pick_slot compares against all four).
+inline int64_t ste_layout(SteLaunch& L, bool allow_inplace) {
+    int64_t blk = 0;
+    for (int i = 0; i < 1 + MAX_MORE; ++i) {
+        if (i >= L.n) {
+            L.t[i] = SteSlot{};
+            L.t[i].blk_begin = INT64_MAX;
+            continue;
+        }
+        L.t[i].blk_begin = blk;
+        L.t[i].inplace = allow_inplace && L.t[i].gx == (const void*)L.t[i].g;
+        blk += L.t[i].inplace ? (L.t[i].rows + STE_THREADS - 1) / STE_THREADS : L.t[i].rows;
+    }
+    return blk;
+}
+#define FQ_LAUNCH2(kern, gx_, gy_, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(gx_), (unsigned)(gy_)), dim3(block), 0, st, __VA_ARGS__)
+
+template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
     clear_stale_error();
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
-    if (!mrw || !(aligned16(g) && aligned16(gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape/alignment not served");
-    SteMore sec{};
-    sec.rows0 = rows;
-    if (more) sec = *more;
-    for (int i = 0; i < sec.n; ++i)
-        if (!(aligned16(sec.t[i].g) && aligned16(sec.t[i].gx))) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served");
+    if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape not served");
+    for (int i = 0; i < L.n; ++i)
+        if (!(aligned16(L.t[i].g) && aligned16(L.t[i].gx) && (reinterpret_cast<uintptr_t>(L.t[i].mask) & 7u) == 0))
+            return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served (g / gx 16 bytes, mask 8 bytes)");
     const int64_t nvec_row = cols / EPV;
     const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
     int cv = (int)((nvec_row + chunks - 1) / chunks);
-    cv = (cv + 63) / 64 * 64;  // every wave covers exactly one 64-vector mask group per slot
+    cv = (cv + 63) / 64 * 64;  // whole waves per slot
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
-    if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-    const int64_t big_rows = largest_rows(sec, rows);
+    const int64_t grid = ste_layout(L, true);
+    if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows exceed the grid limit");
+    int64_t big_rows = 0;  // cache policy follows the largest tensor that is actually streamed
+    for (int i = 0; i < L.n; ++i)
+        if (!L.t[i].inplace && L.t[i].rows > big_rows) big_rows = L.t[i].rows;
     const int64_t bytes = big_rows * cols * T::ESIZE;
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
-#define S(V)                                                                                                                                         \
-    case V:                                                                                                                                          \
-        if (ntl) FQ_LAUNCH((ste_mask_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);        \
-        else if (nts) FQ_LAUNCH((ste_mask_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);  \
-        else FQ_LAUNCH((ste_mask_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nvec_row, chunks, cv, bounds, mask, mrw, lo, hi, sec);          \
+#define S(V)                                                                                                               \
+    case V:                                                                                                                \
+        if (ntl) FQ_LAUNCH2((ste_mask_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);        \
+        else if (nts) FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);  \
+        else FQ_LAUNCH2((ste_mask_kernel<DT, V, false, false>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);          \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
     return launch_result();
 }
 
-template <int DT>
-int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds, const uint64_t* mask,
-                         hipStream_t st, const SteMore* more) {
+template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
     clear_stale_error();
     if constexpr (T::ESIZE != 2) {
@@ -302,26 +317,23 @@ int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, fl
     } else {
         const int64_t mrw = mask_row_words(cols, T::ESIZE);
         auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
-        if (!mrw || cols > 32768 || !(aligned16(g) && al8(gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: shape/alignment not served");
-        SteMore sec{};
-        sec.rows0 = rows;
-        if (more) sec = *more;
-        for (int i = 0; i < sec.n; ++i)
-            if (!(aligned16(sec.t[i].g) && al8(sec.t[i].gx))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
+        if (!mrw || cols > 32768) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: shape not served");
+        for (int i = 0; i < L.n; ++i)
+            if (!(aligned16(L.t[i].g) && al8(L.t[i].gx) && al8(L.t[i].mask))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
         const int64_t nh_row = cols / 4;
         const int64_t chunks = (nh_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
         int ch = (int)((nh_row + chunks - 1) / chunks);
-        ch = (ch + 63) / 64 * 64;  // every wave covers exactly one 64-half-vector mask group per slot
+        ch = (ch + 63) / 64 * 64;
         const int hpt = (ch + STE_THREADS - 1) / STE_THREADS;
-        if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
-        const int64_t big_rows = largest_rows(sec, rows);
-        const int64_t bytes = big_rows * cols * 4;  // the fp32 gradient is the larger stream
+        const int64_t grid = ste_layout(L, false);
+        if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows exceed the grid limit");
+        const int64_t bytes = largest_rows(L) * cols * 4;  // the fp32 gradient is the larger stream
         const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= 2 * NT_STORE_MIN_BYTES;
-#define S(V)                                                                                                                                           \
-    case V:                                                                                                                                            \
-        if (ntl) FQ_LAUNCH((ste_mask_wide_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);        \
-        else if (nts) FQ_LAUNCH((ste_mask_wide_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);  \
-        else FQ_LAUNCH((ste_mask_wide_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, gx, nh_row, chunks, ch, bounds, mask, mrw, lo, hi, sec);          \
+#define S(V)                                                                                                                  \
+    case V:                                                                                                                   \
+        if (ntl) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);        \
+        else if (nts) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);  \
+        else FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, false>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);          \
         break;
         switch (hpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -358,15 +370,23 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
     if (!(aligned16(w) && aligned16(out) && cols % EPV == 0 && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "fused 1-/2-bit branch: rows must be 16-byte aligned and fit the register kernels");
     if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);
     const bool dev = sem == FQ_SEM_DEVICE_EAGER;
-#define R(TPR, V)                                                                                                                         \
-    case V:                                                                                                                               \
-        if (w_bits == 1) {                                                                                                                \
-            if (dev) FQ_LAUNCH((w12_row_kernel<DT, 1, TPR, V, true>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);  \
-            else FQ_LAUNCH((w12_row_kernel<DT, 1, TPR, V, false>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);    \
-        } else {                                                                                                                          \
-            if (dev) FQ_LAUNCH((w12_row_kernel<DT, 2, TPR, V, true>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);  \
-            else FQ_LAUNCH((w12_row_kernel<DT, 2, TPR, V, false>), (TPR == 64 ? (rows + 3) / 4 : rows), (TPR == 64 ? 256 : TPR), st, w, out, scale_out, rows, cols, cv);    \
-        }                                                                                                                                 \
+    const int64_t bytes = rows * cols * T::ESIZE;
+    const int nt = bytes >= NT_LOAD_MIN_BYTES ? 2 : bytes >= NT_STORE_MIN_BYTES ? 1 : 0;  // cache policy as launch_reg's
+#define K(TPR, V, WB, DEV)                                                                                                                   \
+    {                                                                                                                                        \
+        const int64_t grid = TPR == 64 ? (rows + 3) / 4 : rows;                                                                              \
+        constexpr int BLK = TPR == 64 ? 256 : TPR;                                                                                           \
+        if (nt == 2) FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, true, true>), grid, BLK, st, w, out, scale_out, rows, cols, cv);          \
+        else if (nt == 1) FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, false, true>), grid, BLK, st, w, out, scale_out, rows, cols, cv);    \
+        else FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, false, false>), grid, BLK, st, w, out, scale_out, rows, cols, cv);                \
+    }
+#define R(TPR, V)                                                    \
+    case V:                                                          \
+        if (w_bits == 1) {                                           \
+            if (dev) K(TPR, V, 1, true) else K(TPR, V, 1, false)     \
+        } else {                                                     \
+            if (dev) K(TPR, V, 2, true) else K(TPR, V, 2, false)     \
+        }                                                            \
         break;
     if (nvec <= 256) {
         switch ((int)((nvec + 63) / 64)) { R(64, 1) R(64, 2) R(64, 3) R(64, 4) }
@@ -378,6 +398,7 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
         switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
     }
 #undef R
+#undef K
     return launch_result();
 }
 
@@ -386,8 +407,8 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
     template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
     template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
-    template int launch_ste_mask<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
-    template int launch_ste_mask_wide<DT>(const void*, void*, int64_t, int64_t, float, float, const float*, const uint64_t*, hipStream_t, const SteMore*); \
+    template int launch_ste_mask<DT>(SteLaunch, int64_t, float, float, hipStream_t);                             \
+    template int launch_ste_mask_wide<DT>(SteLaunch, int64_t, float, float, hipStream_t);                        \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);     \
     template int launch_w12_rows<DT>(const void*, void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
 

@@ -23,15 +23,17 @@ struct ExportArgs {
     float* scales;       // [rows][2]: Sym {s, t2 = s + 1e-6};  Asym {alpha + 1e-8, beta}
     int32_t* overflow;   // [rows] elements saturated by the container (optional)
     float* bounds;       // optional [rows][2], as row_reg_kernel
-    uint64_t* mask;      // optional STE bit mask, row_reg_kernel's layout
+    uint64_t* mask;      // optional STE bit mask (the row bitmap of fq_kernels.h)
     int64_t mask_row_words;
     float lo, hi;
+    uint32_t clipk;      // integer form of the clip (16-bit tensors), as RowArgs::clipk
     int64_t rows, cols;
     int64_t row_bytes;   // bins row stride in bytes
     SymConst sym;
     AsymConst asym;
     int container;
     int autocast;        // Sym on 16-bit tensors: the reference's arithmetic under CUDA autocast (fp32 behind the reciprocal)
+    int wide_st;         // bin rows are 16-byte aligned (bins base and row stride): 16-byte stores after a lane exchange
     float cmin, cmax;    // container range as floats: Sym signed [-2^(b-1), 2^(b-1)-1], Asym unsigned [0, 2^b - 1]
 };
 
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
 
     const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
     const bool sym_clip = a.lo == -a.hi;
-    uint64_t* mrow = a.mask + row * a.mask_row_words;
+    const uint32_t clipk = (ub != ub) ? 0u : a.clipk;
+    uint8_t* mrow = (uint8_t*)(a.mask + row * a.mask_row_words);
     const int cont = a.container;
     // Sym: only the positive side can exceed a signed container whose top bin is cmax + 1 (-128 fits int8, +128 does not)
     const bool count = cont != BINS_NONE && !(top <= a.cmax);  // block-uniform; true for a NaN row
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
     }
     char* brow = (char*)a.bins + row * a.row_bytes;
     uint32_t nbad = 0;  // wave-uniform
+    uint32_t pk[VPT][4] = {};  // this lane's packed bins per slot (EPV * container bits / 32 dwords used)
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int v = t + i * TPR;
@@ -167,12 +171,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
 #pragma unroll
             for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
         }
-        if (want_mask && (v - (t & 63) < nvec)) {
-            const int vc = v < nvec ? v : nvec - 1;
-            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(vc >> 6) * EPV;
-            if (sym_clip) ste_mask_store<EPV, true>(f, a.lo, a.hi, gw, t & 63);
-            else ste_mask_store<EPV, false>(f, a.lo, a.hi, gw, t & 63);
-        }
+        if (want_mask) ste_mask_record<DT>(mrow, v, v < nvec, r[i], f, a.lo, a.hi, sym_clip, clipk);
         if (cont == BINS_NONE) continue;
         int q[EPV];
         if (!count) {
@@ -200,29 +199,73 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
                 nbad += (uint32_t)__popcll(__ballot(bad && v < nvec));
             }
         }
-        if (v < nvec) {
-            if (cont == BINS_INT8) {
-                uint32_t o[EPV / 4];
+        // pack this slot's bins; the stores follow the loop (lanes trade packed dwords so that each store is 16 bytes)
+        if (cont == BINS_INT8) {
 #pragma unroll
-                for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
-                    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * d + 1], (uint32_t)q[4 * d], 0x0c0c0400u);
-                    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * d + 3], (uint32_t)q[4 * d + 2], 0x04000c0cu);
-                    o[d] = lo | hi;
+            for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
+                const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * d + 1], (uint32_t)q[4 * d], 0x0c0c0400u);
+                const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * d + 3], (uint32_t)q[4 * d + 2], 0x04000c0cu);
+                pk[i][d] = lo | hi;
+            }
+        } else if (cont == BINS_INT4) {
+            uint32_t o = (uint32_t)q[0] & 0xFu;
+#pragma unroll
+            for (int e = 1; e < EPV; ++e) o |= ((uint32_t)q[e] & 0xFu) << (4 * e);
+            pk[i][0] = o;
+        } else {  // BINS_INT16
+#pragma unroll
+            for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm((uint32_t)q[2 * d + 1], (uint32_t)q[2 * d], 0x05040100u);
+        }
+    }
+    // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16.  Writing 8 or 4
+    // bytes per lane makes every wave-instruction cover half / a quarter of each 128-byte line (int8 26.5 us, int4 22.6 us on
+    // [4096,11008] bf16 in round 2), so neighbouring lanes trade dwords first: lane pairs over two slots (8-byte vectors) or
+    // quads over four slots (4-byte vectors), and every storing lane writes 16 contiguous bytes of one slot.  Needs 16-byte
+    // aligned bin rows (a.wide_st, decided on the host; whole pairs / quads of vectors then exist); otherwise the narrow stores.
+    if (cont != BINS_NONE) {
+        const int vb = cont == BINS_INT4 ? EPV / 2 : cont == BINS_INT8 ? EPV : 2 * EPV;  // bytes per vector
+        if (vb == 16) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int v = t + i * TPR;
+                if (v < nvec) st16<true>((uint4*)brow + v, make_uint4(pk[i][0], pk[i][1], pk[i][2], pk[i][3]));
+            }
+        } else if (vb == 8 && a.wide_st) {
+            const bool odd = t & 1;
+#pragma unroll
+            for (int i = 0; i < VPT; i += 2) {
+                if (i + 1 < VPT) {  // even lanes finish slot i, odd lanes slot i + 1
+                    const uint32_t r0 = dpp<0xB1>(odd ? pk[i][0] : pk[i + 1][0]), r1 = dpp<0xB1>(odd ? pk[i][1] : pk[i + 1][1]);
+                    const uint4 o = odd ? make_uint4(r0, r1, pk[i + 1][0], pk[i + 1][1]) : make_uint4(pk[i][0], pk[i][1], r0, r1);
+                    const int v = odd ? t + (i + 1) * TPR : t + i * TPR;
+                    if (v < nvec) st16<true>((uint4*)(brow + (int64_t)(v & ~1) * 8), o);
+                } else {            // odd slot count: the last slot is finished by the even lanes alone
+                    const uint32_t r0 = dpp<0xB1>(pk[i][0]), r1 = dpp<0xB1>(pk[i][1]);
+                    const int v = t + i * TPR;
+                    if (!odd && v < nvec) st16<true>((uint4*)(brow + (int64_t)v * 8), make_uint4(pk[i][0], pk[i][1], r0, r1));
                 }
-                if constexpr (EPV == 8) st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
-                else __builtin_nontemporal_store(o[0], (uint32_t*)brow + v);
-            } else if (cont == BINS_INT4) {
-                uint32_t o = (uint32_t)q[0] & 0xFu;
+            }
+        } else if (vb == 4 && a.wide_st) {
+            const bool l1 = t & 1, l2 = t & 2;
 #pragma unroll
-                for (int e = 1; e < EPV; ++e) o |= ((uint32_t)q[e] & 0xFu) << (4 * e);
-                if constexpr (EPV == 8) __builtin_nontemporal_store(o, (uint32_t*)brow + v);
-                else __builtin_nontemporal_store((uint16_t)o, (uint16_t*)brow + v);
-            } else {  // BINS_INT16
-                uint32_t o[EPV / 2];
+            for (int i = 0; i < VPT; i += 4) {  // 4 x 4 transpose inside each quad: lane j of the quad finishes slot i + j
+                const uint32_t m0 = pk[i][0], m1 = pk[i + 1 < VPT ? i + 1 : i][0], m2 = pk[i + 2 < VPT ? i + 2 : i][0], m3 = pk[i + 3 < VPT ? i + 3 : i][0];
+                const uint32_t ra = dpp<0xB1>(l1 ? m0 : m1), rb = dpp<0xB1>(l1 ? m2 : m3);
+                const uint32_t a0 = l1 ? ra : m0, a1 = l1 ? m1 : ra, b0 = l1 ? rb : m2, b1 = l1 ? m3 : rb;
+                const uint32_t r0 = dpp<0x4E>(l2 ? a0 : b0), r1 = dpp<0x4E>(l2 ? a1 : b1);
+                const uint4 o = l2 ? make_uint4(r0, r1, b0, b1) : make_uint4(a0, a1, r0, r1);
+                const int slot = i + (t & 3);
+                const int vq = (t & ~3) + slot * TPR;  // first vector of this quad in that slot
+                if (slot < VPT && vq < nvec) st16<true>((uint4*)(brow + (int64_t)vq * 4), o);
+            }
+        } else {
 #pragma unroll
-                for (int d = 0; d < EPV / 2; ++d) o[d] = __builtin_amdgcn_perm((uint32_t)q[2 * d + 1], (uint32_t)q[2 * d], 0x05040100u);
-                if constexpr (EPV == 8) st16<true>((uint4*)brow + v, make_uint4(o[0], o[1], o[2], o[3]));
-                else st8<true>((uint2*)brow + v, make_uint2(o[0], o[1]));
+            for (int i = 0; i < VPT; ++i) {
+                const int v = t + i * TPR;
+                if (v >= nvec) continue;
+                if (vb == 8) st8<true>((uint2*)brow + v, make_uint2(pk[i][0], pk[i][1]));
+                else if (vb == 4) __builtin_nontemporal_store(pk[i][0], (uint32_t*)brow + v);
+                else __builtin_nontemporal_store((uint16_t)pk[i][0], (uint16_t*)brow + v);
             }
         }
     }

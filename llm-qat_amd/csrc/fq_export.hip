@@ -75,6 +75,7 @@ int export_entry(const void* x, void* bins, float* scales, int32_t* overflow, in
     a.rows = rows;
     a.cols = cols;
     a.row_bytes = export_row_bytes(cols, container);
+    a.wide_st = (aligned16(bins) && a.row_bytes % 16 == 0) ? 1 : 0;
     a.sym = c.sym;
     a.asym = c.asym;
     a.container = container;
@@ -91,6 +92,7 @@ int export_entry(const void* x, void* bins, float* scales, int32_t* overflow, in
         a.mask_row_words = mrw;
         a.lo = host_rb(lo, dtype);
         a.hi = host_rb(hi, dtype);
+        a.clipk = ste_clip_key(a.lo, a.hi, dtype);
     }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {

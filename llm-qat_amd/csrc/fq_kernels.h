@@ -15,6 +15,7 @@
 #pragma once
 #include "fq_device.h"
 
+
 namespace fq {
 
 constexpr int MAX_MORE = 3;  // up to 4 tensors per launch (q/k/v weights + their shared input)
@@ -39,10 +40,11 @@ struct RowArgs {
     AsymConst asym;
     // optional STE mask (register-resident kernels only): one bit per element, set where the
     // backward must zero the gradient (x >= hi || x <= lo).  Written only for rows whose bounds
-    // do not already prove that nothing is clipped.  Layout: see ste_mask_store().
+    // do not already prove that nothing is clipped.  Layout: a plain bitmap per row, see ste_mask_record().
     uint64_t* mask;
     int64_t mask_row_words;
     float lo, hi;
+    uint32_t clipk;  // integer form of the clip for 16-bit tensors (ste_flags16_*), 0 = compare as floats
     // optional FURTHER tensors of the same launch (register-resident Sym kernels only): same dtype and cols (so the same
     // launch shape), each with its own rows / bit width / outputs.  QuantizeLinear needs its weight [out, in] and its input
     // [tokens, in] fake-quantized at the same moment and both reduce over `in`; sibling projections (q/k/v, gate/up) add
@@ -53,63 +55,80 @@ struct RowArgs {
     TensorSlot more[MAX_MORE];
 };
 
-// STE bit mask layout (private to the forward/backward kernel pair, independent of launch shape):
-// the row's 16-byte vectors are taken in groups of 64 (one per lane of a wave); group G owns EPV
-// consecutive 64-bit words, word e holding, at bit l, the flag of element e of vector 64*G + l.
-// That is exactly what one __ballot per element position produces -- no bit transposes.
-// f = the vector's elements (already unpacked); SYMCLIP: lo == -hi, one |x| >= hi compare per element
-// (abs is a free source modifier; NaN compares false, i.e. passes the gradient, as in the reference).
-template <int N, bool SYMCLIP>
-__device__ __forceinline__ void ste_mask_store(const float (&f)[N], float lo, float hi, uint64_t* gw, int lane) {
-    uint64_t mine = 0;
+// STE bit mask: a plain bitmap per row.  Row r starts at mask + r * mask_row_words 64-bit words (mask_row_words =
+// ceil(cols / 64)); bit (j % 8) of byte (j / 8) is the flag of element j: 1 = the backward zeroes the gradient
+// (x >= hi || x <= lo; NaN compares false, i.e. passes the gradient, as in the reference).  One layout for every forward
+// (16-byte vectors of 16-bit or fp32 elements, the fp32-result kernel's 8-byte half-vectors) and every backward, so any
+// mask-consuming kernel can serve any mask-producing one.  Everything is lane-local: a lane derives the flags of its
+// own vector and stores its own byte (bf16 / fp16: 8 elements = one byte; 4-element lanes -- fp32 vectors, half-vectors --
+// hand their nibble to the even neighbour first), and the backward lane loads that byte back next to its gradient.
+// Round 2 built the words with one __ballot per element position (8 v_cmp + 16 v_cndmask per vector to route the
+// ballots to their storing lanes, and 16 v_readlane per vector in the backward); this costs 15 / 13 VALU ops per vector.
+//
+// Integer form of the predicate for 16-bit tensors (the usual clip: lo == -hi, hi >= 0, no NaN in the row): with
+// a = bits & 0x7FFF (sign-magnitude order, |x| as an integer) and T = bits(hi),  |x| >= hi  <=>  a >= T  <=>  bit 15 of
+// a + (0x8000 - T); both halves of a dword at once with one AND and one ADD (no carry crosses the halves: a + K <= 0xFFFF).
+// v_perm_b32 gathers the four high bytes of two dwords, v_dot4_u32_u8 weighs the flag bits (bit 7 of each byte) into place.
+// clipk = (0x8000 - T) in both halves; 0 = not applicable (host: fq_launch.h ste_clip_key).
+__device__ __forceinline__ uint32_t ste_flags16_pair(uint32_t w0, uint32_t w1, uint32_t clipk) {   // 4 elements -> low nibble
+    const uint32_t s0 = (w0 & 0x7FFF7FFFu) + clipk, s1 = (w1 & 0x7FFF7FFFu) + clipk;
+    const uint32_t p = __builtin_amdgcn_perm(s1, s0, 0x07050301u) & 0x80808080u;   // bytes: s0.b1, s0.b3, s1.b1, s1.b3
+    return __builtin_amdgcn_udot4(p, 0x08040201u, 0u, false) >> 7;
+}
+__device__ __forceinline__ uint32_t ste_flags16_vec(const uint4& w, uint32_t clipk) {   // 8 elements -> one byte
+    const uint32_t s0 = (w.x & 0x7FFF7FFFu) + clipk, s1 = (w.y & 0x7FFF7FFFu) + clipk;
+    const uint32_t s2 = (w.z & 0x7FFF7FFFu) + clipk, s3 = (w.w & 0x7FFF7FFFu) + clipk;
+    const uint32_t p = __builtin_amdgcn_perm(s1, s0, 0x07050301u) & 0x80808080u;
+    const uint32_t q = __builtin_amdgcn_perm(s3, s2, 0x07050301u) & 0x80808080u;
+    return __builtin_amdgcn_udot4(q, 0x80402010u, __builtin_amdgcn_udot4(p, 0x08040201u, 0u, false), false) >> 7;
+}
+// general form (any clip, NaN rows, fp32 tensors): compare the unpacked values
+template <int N, bool SYMCLIP> __device__ __forceinline__ uint32_t ste_flags_f(const float (&f)[N], float lo, float hi) {
+    uint32_t m = 0;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-        const bool m = SYMCLIP ? (__builtin_fabsf(f[e]) >= hi) : ((f[e] >= hi) || (f[e] <= lo));
-        const uint64_t b = __ballot(m);
-        if (lane == e) mine = b;
+        const bool z = SYMCLIP ? (__builtin_fabsf(f[e]) >= hi) : ((f[e] >= hi) || (f[e] <= lo));
+        m |= z ? (1u << e) : 0u;
     }
-    if (lane < N) gw[lane] = mine;
+    return m;
 }
-// 64-bit value of lane `l` (compile-time constant) as a wave-uniform scalar
-template <int L> __device__ __forceinline__ uint64_t readlane64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, L);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), L);
-    return ((uint64_t)hi << 32) | lo;
-}
-// The mask words of ALL of a wave's slots in one 8-byte vector load per lane, issued next to the gradient loads:
-// lane l holds word (l % WPG) of slot (l / WPG)'s group (WPG = words per group).  Fetching them slot by slot instead
-// puts a dependent memory round trip in front of every store (the compiler turns those wave-uniform loads into
-// VMEM loads + v_readfirstlane, serialised by vmcnt behind everything issued before them).
-template <int WPG, int SLOTS, int STRIDE>
-__device__ __forceinline__ uint64_t ste_mask_prefetch(const uint64_t* mrow, int64_t first, int t, int n) {
-    static_assert(SLOTS * WPG <= 64, "one word per lane");
-    const int lane = t & 63, slot = lane / WPG, e = lane % WPG;
-    if (slot >= SLOTS) return 0;
-    int v = (t - lane) + slot * STRIDE;  // the wave's first vector of that slot
-    v = v < n ? v : n - 1;
-    return mrow[((first + v) >> 6) * WPG + e];
-}
-template <int WPG, int I, int E = 0> __device__ __forceinline__ void ste_mask_words(uint64_t held, uint64_t (&mw)[WPG]) {
-    if constexpr (E < WPG) {
-        mw[E] = readlane64<I * WPG + E>(held);
-        ste_mask_words<WPG, I, E + 1>(held, mw);
+// nibbles of a lane pair -> the even lane's byte (the odd lane's return value is not used)
+__device__ __forceinline__ uint32_t ste_nibble_pair(uint32_t nib) { return nib | (dpp<0xB1>(nib) << 4); }   // quad_perm:[1,0,3,2]
+
+// Flags of this lane's 16-byte vector `v` of the row (f = its unpacked elements, raw = its dwords) into the row's bitmap.
+// in_range: v < nvec (lanes holding a clamped duplicate of the last vector contribute nothing).
+template <int DT> __device__ __forceinline__ void ste_mask_record(uint8_t* mrow, int v, bool in_range, const uint4& raw,
+                                                                  const float (&f)[16 / Ty<DT>::ESIZE], float lo, float hi, bool sym_clip,
+                                                                  uint32_t clipk /* 0 unless the integer form applies to this row */) {
+    if constexpr (Ty<DT>::ESIZE == 2) {
+        uint32_t m;
+        if (clipk) m = ste_flags16_vec(raw, clipk);          // wave-uniform choice
+        else m = sym_clip ? ste_flags_f<8, true>(f, lo, hi) : ste_flags_f<8, false>(f, lo, hi);
+        if (in_range) mrow[v] = (uint8_t)m;
+    } else {
+        uint32_t nib = sym_clip ? ste_flags_f<4, true>(f, lo, hi) : ste_flags_f<4, false>(f, lo, hi);
+        nib = in_range ? nib : 0u;
+        const uint32_t byte = ste_nibble_pair(nib);
+        if (in_range && !(v & 1)) mrow[v >> 1] = (uint8_t)byte;
     }
 }
 
-// apply group mask words (wave-uniform, in SGPRs) to this lane's gradient vector.  inverse_ballot turns a 64-bit
-// wave mask straight into a per-lane predicate, so each half-dword costs one v_cndmask with the SGPR pair as the
-// selector (and gfx950's v_bitop3 folds the two ANDs): 3 VALU ops per dword instead of a shift/and/compare chain.
-template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g, const uint64_t* mw) {
-    using T = Ty<DT>;
+// Backward side: this lane's flag byte -> its gradient vector with the flagged elements zeroed.
+//   16-bit: m2 = m | m << 15 holds flag k at bits k and k + 15, so (m2 << (15 - 2d)) has the flags of dword d's two
+//   halves at bits 15 and 31; v_pk_ashrrev_i16 by 15 smears each into its half; v_bfi clears: 3 VALU ops per dword.
+template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g, uint32_t m /* 8 (4 for fp32) flag bits */) {
     uint32_t w[4] = {g.x, g.y, g.z, g.w};
+    if constexpr (Ty<DT>::EPD == 1) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        if constexpr (T::EPD == 1) {
-            w[d] = __builtin_amdgcn_inverse_ballot_w64(mw[d]) ? 0u : w[d];
-        } else {
-            const uint32_t k0 = __builtin_amdgcn_inverse_ballot_w64(mw[2 * d]) ? 0xFFFF0000u : 0xFFFFFFFFu;
-            const uint32_t k1 = __builtin_amdgcn_inverse_ballot_w64(mw[2 * d + 1]) ? 0x0000FFFFu : 0xFFFFFFFFu;
-            w[d] &= k0 & k1;
+        for (int d = 0; d < 4; ++d) w[d] = ((m >> d) & 1u) ? 0u : w[d];
+    } else {
+        typedef short s16x2_t __attribute__((ext_vector_type(2)));
+        const uint32_t m2 = m | (m << 15);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const s16x2_t t = __builtin_bit_cast(s16x2_t, m2 << (15 - 2 * d));
+            const uint32_t z = __builtin_bit_cast(uint32_t, t >> (short)15);   // v_pk_ashrrev_i16
+            w[d] &= ~z;
         }
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
@@ -261,7 +280,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     // Elementwise pass.  Rows that can actually be clipped also emit the STE bit mask for the backward.
     const bool want_mask = msk && !((ub < a.hi) && (lb > a.lo));  // wave-uniform
     const bool sym_clip = a.lo == -a.hi;
-    uint64_t* mrow = msk + row * a.mask_row_words;
+    const uint32_t clipk = (ub != ub) ? 0u : a.clipk;  // a row with a NaN compares as floats (NaN passes the gradient)
+    uint8_t* mrow = (uint8_t*)(msk + row * a.mask_row_words);
     int32_t* idxr = (DBG && a.idx) ? a.idx + row * a.cols : nullptr;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -275,12 +295,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 #pragma unroll
             for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
         }
-        if (want_mask && (v - (t & 63) < nvec)) {  // wave-uniform: this wave's 64-vector group exists
-            const int vc = v < nvec ? v : nvec - 1;  // r[i] holds vector vc (clamped load)
-            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(vc >> 6) * EPV;
-            if (sym_clip) ste_mask_store<EPV, true>(f, a.lo, a.hi, gw, t & 63);
-            else ste_mask_store<EPV, false>(f, a.lo, a.hi, gw, t & 63);
-        }
+        if (want_mask) ste_mask_record<DT>(mrow, v, v < nvec, r[i], f, a.lo, a.hi, sym_clip, clipk);
         if constexpr (AC != 0) {  // fp32 arithmetic behind the reciprocal, as autocast makes the reference do
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[e] = sym_elem_autocast(f[e], sr);
@@ -333,10 +348,9 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
 // half-vectors (4 elements per lane, 512 B contiguous per wave-instruction) so that each lane's 4 fp32 results
 // are one 16-byte store and a wave-instruction writes 1 KiB contiguous.  (Keeping the 16-byte loads makes every
 // store instruction touch half of each 128-byte line: 99 us instead of ~50 us on the 90 MB tensor.)
-// Records row bounds and, on request, the STE mask in its own "half-vector" layout (the 4 elements of a lane's
-// 8-byte load take the place of the 16-byte vector's EPV elements: groups of 64 half-vectors, 4 words per group;
-// never more words per row than the 16-byte layout, so fq_ste_mask_bytes() sizes both).  Its consumer is
-// ste_mask_wide_kernel, whose fp32 gradient is read with the same 4-elements-per-lane mapping.
+// Records row bounds and, on request, the STE mask (the row bitmap every kernel shares: a lane's 4 elements are one
+// nibble, lane pairs assemble a byte).  Its usual consumer is ste_mask_wide_kernel, whose fp32 gradient is read with
+// the same 4-elements-per-lane mapping.
 // Serves two tensors per launch like row_reg_kernel (the K and V hooks: modeling_llama_quant.py:320-327).
 // ------------------------------------------------------------------------------------
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -414,7 +428,8 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
     }
     const bool want_mask = MASK && msk && !((m < a.hi) && (-m > a.lo));  // wave-uniform; NaN row: mask written, all bits 0
     const bool sym_clip = a.lo == -a.hi;
-    uint64_t* mrow = msk + row * a.mask_row_words;
+    const uint32_t clipk = (m != m) ? 0u : a.clipk;
+    uint8_t* mrow = (uint8_t*)(msk + row * a.mask_row_words);
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
         const int h = t + i * TPR;
@@ -425,11 +440,13 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
             T::unpack(r[i].y, f1);
             f[0] = f0[0], f[1] = f0[1], f[2] = f1[0], f[3] = f1[1];
         }
-        if (MASK && want_mask && (h - (t & 63) < nh)) {  // wave-uniform: this wave's 64-half-vector group exists
-            const int hc = h < nh ? h : nh - 1;
-            uint64_t* gw = mrow + (int64_t)__builtin_amdgcn_readfirstlane(hc >> 6) * 4;
-            if (sym_clip) ste_mask_store<4, true>(f, a.lo, a.hi, gw, t & 63);
-            else ste_mask_store<4, false>(f, a.lo, a.hi, gw, t & 63);
+        if (MASK && want_mask) {  // half-vector h = elements 4h .. 4h+3 = nibble (h & 1) of the bitmap's byte h / 2
+            uint32_t nib;
+            if (clipk) nib = ste_flags16_pair(r[i].x, r[i].y, clipk);
+            else nib = sym_clip ? ste_flags_f<4, true>(f, a.lo, a.hi) : ste_flags_f<4, false>(f, a.lo, a.hi);
+            nib = h < nh ? nib : 0u;
+            const uint32_t byte = ste_nibble_pair(nib);
+            if (h < nh && !(h & 1)) mrow[h >> 1] = (uint8_t)byte;
         }
         const uint4 o = make_uint4(as_u(sym_elem_autocast(f[0], sr)), as_u(sym_elem_autocast(f[1], sr)),
                                    as_u(sym_elem_autocast(f[2], sr)), as_u(sym_elem_autocast(f[3], sr)));
@@ -850,21 +867,19 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
         const int64_t nvec_row = cols / EPV, nvec = rows * nvec_row;
         const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (v >= nvec) return;
-        const float sc = T::load1(scale, scale_per_row ? v / nvec_row : 0);
-        const float rsc = 1.0f / sc;
-        const bool mk = div_exact_ok(sc);
+        const W12Row wr = w12_row<DT>(T::load1(scale, scale_per_row ? v / nvec_row : 0), cv);
         const uint4 r = ((const uint4*)w)[v];
         const uint32_t in[4] = {r.x, r.y, r.z, r.w};
-        uint32_t o[4];
+        uint4 o;
+        if (__builtin_amdgcn_ballot_w64(!wr.mk) == 0) {  // every lane's row has an ordinary scale (a wave can straddle rows)
+            o = w12_vec<DT, WBITS>(r, wr, cv);
+        } else {
+            uint32_t od[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            float f[T::EPD];
-            T::unpack(in[d], f);
-#pragma unroll
-            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv, rsc, mk);
-            o[d] = T::pack(f);
+            for (int d = 0; d < 4; ++d) od[d] = w12_dword_any<DT, WBITS>(in[d], wr, cv);
+            o = make_uint4(od[0], od[1], od[2], od[3]);
         }
-        ((uint4*)out)[v] = make_uint4(o[0], o[1], o[2], o[3]);
+        ((uint4*)out)[v] = o;
     } else {
         const int64_t n = rows * cols, stride = (int64_t)gridDim.x * 256;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -880,7 +895,7 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
 // floating-point sum depends on its order: for 16-bit tensors the fp32 sum is rounded to 8 / 11 significant bits, so two
 // orders disagree only when the sum lies within ~2^-20 of a rounding boundary (about one row in a few thousand); for fp32
 // tensors the last bit differs routinely.  That is why this path is opt-in and ATen's reduction stays the default.
-template <int DT, int WBITS, int TPR, int VPT, bool DEVSEM>
+template <int DT, int WBITS, int TPR, int VPT, bool DEVSEM, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const void* __restrict__ w, void* __restrict__ out, void* __restrict__ scale_out,
                                                                         int64_t rows, int64_t cols, float cv) {
     using T = Ty<DT>;
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const vo
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int v = t + i * TPR;
-        r[i] = xr[v < nvec ? v : nvec - 1];
+        r[i] = ld16<NTL>(&xr[v < nvec ? v : nvec - 1]);
         const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -928,106 +943,119 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const vo
     float sc = T::rb(DEVSEM ? acc * (1.0f / (float)cols) : acc / (float)cols);
     if constexpr (WBITS == 2) sc = T::rb(2.0f * sc);
     if (t == 0 && scale_out) T::store1(scale_out, row, sc);
-    const float rsc = 1.0f / sc;
-    const bool mk = div_exact_ok(sc);
+    const W12Row wr = w12_row<DT>(sc, cv);
+    if (wr.mk) {  // wave-uniform: an ordinary scale (every row of a real weight)
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int v = t + i * TPR;
-        const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        uint32_t o[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            float f[T::EPD];
-            T::unpack(wd[d], f);
-#pragma unroll
-            for (int k = 0; k < T::EPD; ++k) f[k] = w12_elem<DT, WBITS>(f[k], sc, cv, rsc, mk);
-            o[d] = T::pack(f);
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * TPR;
+            const uint4 o = w12_vec<DT, WBITS>(r[i], wr, cv);
+            if (v < nvec) st16<NTS>(&yr[v], o);
         }
-        if (v < nvec) yr[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {      // zero / NaN / infinite / extreme scale: the reference chain op for op
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * TPR;
+            const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = w12_dword_any<DT, WBITS>(wd[d], wr, cv);
+            if (v < nvec) st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
+        }
     }
 }
 
 // STE backward from the forward's bit mask: reads g (+ 1 bit/element of mask for rows that can be
-// clipped), never x.  Same row/chunk decomposition as ste_rows_kernel; cv is a multiple of 64 so
-// every wave covers exactly one mask group per slot.
-template <int DT, int VPT, bool NTS, int I = 0>
-__device__ __forceinline__ void ste_mask_slots(const uint4 (&rg)[VPT], uint64_t held, uint4* out, int t, int nvec) {
-    if constexpr (I < VPT) {
-        constexpr int EPV = 16 / Ty<DT>::ESIZE;
-        uint64_t mw[EPV];
-        ste_mask_words<EPV, I>(held, mw);
-        const int v = t + I * STE_THREADS;
-        const uint4 o = ste_mask_apply<DT>(rg[I], mw);
-        if (v < nvec) st16<NTS>(&out[v], o);
-        ste_mask_slots<DT, VPT, NTS, I + 1>(rg, held, out, t, nvec);
-    }
-}
-
-template <int DT, int HPT, bool NTS, int I = 0>
-__device__ __forceinline__ void ste_mask_wide_slots(const uint4 (&rg)[HPT], uint64_t held, uint2* out, int t, int nh) {
-    if constexpr (I < HPT) {
-        using T = Ty<DT>;
-        uint64_t mw[4];
-        ste_mask_words<4, I>(held, mw);
-        const int h = t + I * STE_THREADS;
-        const float f0[2] = {as_f(rg[I].x), as_f(rg[I].y)}, f1[2] = {as_f(rg[I].z), as_f(rg[I].w)};
-        uint32_t w0 = T::pack(f0), w1 = T::pack(f1);
-        w0 &= (__builtin_amdgcn_inverse_ballot_w64(mw[0]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
-              (__builtin_amdgcn_inverse_ballot_w64(mw[1]) ? 0x0000FFFFu : 0xFFFFFFFFu);
-        w1 &= (__builtin_amdgcn_inverse_ballot_w64(mw[2]) ? 0xFFFF0000u : 0xFFFFFFFFu) &
-              (__builtin_amdgcn_inverse_ballot_w64(mw[3]) ? 0x0000FFFFu : 0xFFFFFFFFu);
-        if (h < nh) st8<NTS>(&out[h], make_uint2(w0, w1));
-        ste_mask_wide_slots<DT, HPT, NTS, I + 1>(rg, held, out, t, nh);
-    }
-}
-
+// clipped), never x.  One launch serves up to 1 + MAX_MORE tensors of the same dtype and cols (a QuantizeLinear's weight and
+// input, a sibling group).  Two kinds of slot:
+//   copying (gx != g)   rows x chunks blocks, block b of the slot = chunk (b % chunks) of row (b / chunks), as ste_rows_kernel.
+//   in place (gx == g)  a weight's gradient handed on by reference: rows whose bounds prove that nothing clips -- all of a
+//                       weight's, in practice -- need nothing at all, so the slot gets one block per STE_THREADS rows: each thread
+//                       reads one row's bounds, and the block then walks the (rare) clippable rows, masking them where they
+//                       stand.  (Round 2 launched rows x chunks blocks that each read 8 bytes and left: 3.7 us of empty blocks
+//                       for a q/k/v group.)  Meant for tensors whose rows rarely clip; an activation gradient belongs in a
+//                       copying slot.
 struct SteSlot {
-    int64_t row_begin;
     const void* g;
     void* gx;
     const float* bounds;
     const uint64_t* mask;
+    int64_t rows;
+    int64_t blk_begin;  // first block of this slot
+    int inplace;
 };
-struct SteMore {  // optional further tensors of a mask-backward launch (same dtype and cols; see RowArgs)
-    int64_t rows0;  // rows of the first tensor (= all rows of the launch when n == 0)
+struct SteLaunch {
     int n;
-    SteSlot t[MAX_MORE];
+    SteSlot t[1 + MAX_MORE];
 };
 
-template <int DT, int VPT, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* g, void* gx, int64_t nvec_row,  // gx may alias g (in place)
-                                                               int64_t chunks, int cv, const float* __restrict__ bounds,
-                                                               const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
-                                                               float hi, SteMore more) {
-    using T = Ty<DT>;
-    constexpr int EPV = 16 / T::ESIZE;
-    int64_t row = blockIdx.x / chunks;
-    if (row >= more.rows0) {  // block-uniform
-        int64_t rbase = 0;
+// The flag bits of a wave's SLOTS slots (slot i = the 64 lane-vectors of EPL elements each that the wave's lanes hold at
+// t + i * STE_THREADS) with ONE dword load per lane and four (eight) slots -- issued next to the gradient loads, before the
+// row's bounds have even arrived -- then one ds_bpermute_b32 per slot (the LDS crossbar, no memory access) to hand every lane
+// the dword that holds its bits.  (A byte load per lane and slot costs a VMEM instruction each: 2-3 % slower on the
+// [2048,4096] launches, profiles/r03_ab_mask_fetch.txt.)  Slot i's bits are a contiguous run of 64 * EPL / 8 bytes of the row
+// bitmap starting at bit (first + (t & ~63) + i * STE_THREADS) * EPL.
+// EPL = elements per lane and slot: 8 (16-bit vectors: a byte per lane) or 4 (fp32 vectors, half-vectors: a nibble).
+// row_dwords: dwords of one bitmap row (reads are clamped to it; bits past the row's end belong to lanes that store nothing).
+template <int EPL, int SLOTS> struct SteMaskHeld {
+    static constexpr int RUN_DW = 64 * EPL / 32;          // dwords per slot run: 16 or 8
+    static constexpr int PER_LOAD = 64 / RUN_DW;          // slots covered by one dword load per lane: 4 or 8
+    static constexpr int NLOAD = (SLOTS + PER_LOAD - 1) / PER_LOAD;
+    uint32_t held[NLOAD];
+    __device__ __forceinline__ void load(const uint8_t* mrow, int64_t first, int row_dwords, int t) {
+        const int lane = t & 63;
+        const int64_t wave_first = first + (t - lane);  // multiple of 64 lane-vectors
+        const uint32_t* md = (const uint32_t*)mrow;
 #pragma unroll
-        for (int i = 0; i < MAX_MORE; ++i) {
-            if (i < more.n && row >= more.t[i].row_begin) {
-                rbase = more.t[i].row_begin;
-                g = more.t[i].g;
-                gx = more.t[i].gx;
-                bounds = more.t[i].bounds;
-                mask = more.t[i].mask;
-            }
+        for (int k = 0; k < NLOAD; ++k) {
+            const int slot = k * PER_LOAD + lane / RUN_DW;
+            int64_t dw = (wave_first + (int64_t)slot * STE_THREADS) * EPL / 32 + lane % RUN_DW;
+            dw = dw < row_dwords ? dw : row_dwords - 1;
+            held[k] = md[dw];
         }
-        row -= rbase;
     }
-    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
-    const bool safe = (ub < hi) && (lb > lo);
-    // In place (gx == g, e.g. a weight's gradient handed on by reference): a row that cannot clip needs nothing at all --
-    // the identity part of the STE costs no traffic.  Block-uniform exit before any vector memory operation.
-    if (safe && gx == (const void*)g) return;
-    const int64_t vs = (blockIdx.x % chunks) * cv;
+    // lane l's bits of a slot sit in dword (l * EPL / 32) of the run, at bit (l * EPL) % 32.  All 64 lanes must be active.
+    __device__ __forceinline__ void bits(int t, uint32_t (&mb)[SLOTS]) const {
+        const int lane = t & 63;
+        const int src = (lane * EPL / 32) * 4, sh = (lane * EPL) % 32;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src + (i % PER_LOAD) * RUN_DW * 4, (int)held[i / PER_LOAD]);
+            mb[i] = (w >> sh) & ((1u << EPL) - 1u);
+        }
+    }
+};
+
+// which tensor of the launch a block belongs to.  Branch-free on purpose: every kernarg field is loaded up front and chosen
+// with scalar selects (a chain of `if (blockIdx >= begin_i) slot = t[i]` compiled to three dependent s_load / s_waitcnt /
+// s_cbranch round trips in the prologue of every block).  Unused slots carry blk_begin = INT64_MAX (host).
+__device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) {
+    static_assert(MAX_MORE == 3, "four slots");
+    const int64_t b1 = L.t[1].blk_begin, b2 = L.t[2].blk_begin, b3 = L.t[3].blk_begin;
+    const int s = (int)(b >= b1) + (int)(b >= b2) + (int)(b >= b3);
+    SteSlot r;
+#define FQ_PICK(f) r.f = s == 0 ? L.t[0].f : s == 1 ? L.t[1].f : s == 2 ? L.t[2].f : L.t[3].f
+    FQ_PICK(g);
+    FQ_PICK(gx);
+    FQ_PICK(bounds);
+    FQ_PICK(mask);
+    FQ_PICK(rows);
+    FQ_PICK(blk_begin);
+    FQ_PICK(inplace);
+#undef FQ_PICK
+    return r;
+}
+
+// one chunk (cv vectors from vector vs) of one row.  `bounds` non-null: the row's {upper, lower} bounds are read HERE, after
+// the gradient and mask loads have been issued, so that nothing waits on them (null: the caller knows the row can clip).
+template <int DT, int VPT, bool NTL, bool NTS>
+__device__ __forceinline__ void ste_mask_chunk(const void* g, void* gx, const uint8_t* mrow, int mrow_dwords, int64_t row, int64_t nvec_row,
+                                               int64_t vs, int cv, const float* bounds, float lo, float hi, int t) {
+    using T = Ty<DT>;
     const int64_t off = row * nvec_row + vs;
     const uint4* gr = (const uint4*)g + off;
     uint4* or_ = (uint4*)gx + off;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
-    const int t = threadIdx.x;
     uint4 rg[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -1035,52 +1063,86 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(const void* g, vo
         v = v < nvec ? v : nvec - 1;
         rg[i] = ld16<NTL>(&gr[v]);
     }
-    if (safe) {
+    SteMaskHeld<16 / T::ESIZE, VPT> mh;
+    mh.load(mrow, vs, mrow_dwords, t);  // unconditionally (a safe row's bitmap is unwritten memory of the same buffer: read, ignored)
+    bool safe = false;
+    if (bounds) {
+        const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+        safe = (ub < hi) && (lb > lo);  // false when a bound is NaN
+    }
+    if (safe) {  // block-uniform
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = t + i * STE_THREADS;
             if (v < nvec) st16<NTS>(&or_[v], rg[i]);
         }
     } else {
-        const uint64_t held = ste_mask_prefetch<EPV, VPT, STE_THREADS>(mask + row * mask_row_words, vs, t, nvec);
-        ste_mask_slots<DT, VPT, NTS>(rg, held, or_, t, nvec);
+        uint32_t mb[VPT];
+        mh.bits(t, mb);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * STE_THREADS;
+            const uint4 o = ste_mask_apply<DT>(rg[i], mb[i]);
+            if (v < nvec) st16<NTS>(&or_[v], o);
+        }
+    }
+}
+
+// grid: x = the slots' row blocks (a copying slot: one per row; an in-place slot: one per STE_THREADS rows), y = chunk of the row
+template <int DT, int VPT, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int64_t nvec_row, int cv, int64_t mask_row_words, float lo, float hi) {
+    __shared__ uint64_t unsafe_rows[STE_THREADS / 64];
+    const int t = threadIdx.x;
+    const SteSlot sl = ste_pick_slot(L, (int64_t)blockIdx.x);
+    const int64_t local = (int64_t)blockIdx.x - sl.blk_begin;
+    if (!sl.inplace) {
+        ste_mask_chunk<DT, VPT, NTL, NTS>(sl.g, sl.gx, (const uint8_t*)(sl.mask + local * mask_row_words), (int)mask_row_words * 2, local, nvec_row,
+                                          (int64_t)blockIdx.y * cv, cv, sl.bounds, lo, hi, t);
+        return;
+    }
+    if (blockIdx.y) return;  // an in-place slot's blocks walk whole rows
+    // in place: which of this block's STE_THREADS rows can clip at all?
+    const int64_t r0 = local * STE_THREADS;
+    bool unsafe = false;
+    if (r0 + t < sl.rows) {
+        const float ub = sl.bounds[2 * (r0 + t)], lb = sl.bounds[2 * (r0 + t) + 1];
+        unsafe = !((ub < hi) && (lb > lo));
+    }
+    const uint64_t bal = __ballot(unsafe);
+    if ((t & 63) == 0) unsafe_rows[t >> 6] = bal;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < STE_THREADS / 64; ++w) {  // block-uniform walk: every wave reaches the end
+        uint64_t bits = unsafe_rows[w];
+        while (bits) {
+            const int64_t row = r0 + w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint8_t* mrow = (const uint8_t*)(sl.mask + row * mask_row_words);
+#pragma unroll 1
+            for (int c = 0; c < (int)gridDim.y; ++c)
+                ste_mask_chunk<DT, VPT, false, false>(sl.g, sl.gx, mrow, (int)mask_row_words * 2, row, nvec_row, (int64_t)c * cv, cv, nullptr, lo, hi, t);
+        }
     }
 }
 
 // STE backward of a fp32-result (autocast) forward: the gradient arrives in fp32 (the dtype of the forward's result),
 // the input's gradient leaves in the input's 16-bit dtype -- the autograd engine's cast and the masking in one pass
-// (read 4 B + write 2 B per element instead of a cast kernel followed by a 16-bit STE kernel).  Mask in the wide
-// forward's layout: half-vectors (4 elements) in groups of 64, 4 words per group.  ch is a multiple of 64.
+// (read 4 B + write 2 B per element instead of a cast kernel followed by a 16-bit STE kernel).  A lane owns 4 elements
+// (one 16-byte fp32 vector in, one 8-byte 16-bit half-vector out) = one nibble of the row bitmap.  ch is a multiple of 64.
+// grid: x = rows of all slots, y = chunk of the row.
 template <int DT, int HPT, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(const void* __restrict__ g, void* __restrict__ gx, int64_t nh_row,
-                                                                    int64_t chunks, int ch, const float* __restrict__ bounds,
-                                                                    const uint64_t* __restrict__ mask, int64_t mask_row_words, float lo,
-                                                                    float hi, SteMore more) {
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(SteLaunch L, int64_t nh_row, int ch, int64_t mask_row_words, float lo, float hi) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "fp32 gradient in, 16-bit gradient out");
-    int64_t row = blockIdx.x / chunks;
-    if (row >= more.rows0) {  // block-uniform
-        int64_t rbase = 0;
-#pragma unroll
-        for (int i = 0; i < MAX_MORE; ++i) {
-            if (i < more.n && row >= more.t[i].row_begin) {
-                rbase = more.t[i].row_begin;
-                g = more.t[i].g;
-                gx = more.t[i].gx;
-                bounds = more.t[i].bounds;
-                mask = more.t[i].mask;
-            }
-        }
-        row -= rbase;
-    }
-    const int64_t hs = (blockIdx.x % chunks) * ch;
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    const SteSlot sl = ste_pick_slot(L, (int64_t)blockIdx.x);
+    const int64_t row = (int64_t)blockIdx.x - sl.blk_begin;
+    const int64_t hs = (int64_t)blockIdx.y * ch;
     const int64_t off = row * nh_row + hs;
-    const uint4* gr = (const uint4*)g + off;
-    uint2* or_ = (uint2*)gx + off;
+    const uint4* gr = (const uint4*)sl.g + off;
+    uint2* or_ = (uint2*)sl.gx + off;
     const int64_t rem = nh_row - hs;
     const int nh = (int)(rem < ch ? rem : ch);
-    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
-    const bool safe = (ub < hi) && (lb > lo);
     const int t = threadIdx.x;
     uint4 rg[HPT];
 #pragma unroll
@@ -1089,16 +1151,25 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(const void* 
         h = h < nh ? h : nh - 1;
         rg[i] = ld16<NTL>(&gr[h]);
     }
-    if (safe) {
+    SteMaskHeld<4, HPT> mh;
+    mh.load((const uint8_t*)(sl.mask + row * mask_row_words), hs, (int)mask_row_words * 2, t);
+    const float ub = sl.bounds[2 * row], lb = sl.bounds[2 * row + 1];
+    const bool safe = (ub < hi) && (lb > lo);
+    uint32_t mb[HPT];
+    if (!safe) mh.bits(t, mb);  // block-uniform
+    else {
 #pragma unroll
-        for (int i = 0; i < HPT; ++i) {
-            const int h = t + i * STE_THREADS;
-            const float f0[2] = {as_f(rg[i].x), as_f(rg[i].y)}, f1[2] = {as_f(rg[i].z), as_f(rg[i].w)};
-            if (h < nh) st8<NTS>(&or_[h], make_uint2(T::pack(f0), T::pack(f1)));
-        }
-    } else {
-        const uint64_t held = ste_mask_prefetch<4, HPT, STE_THREADS>(mask + row * mask_row_words, hs, t, nh);
-        ste_mask_wide_slots<DT, HPT, NTS>(rg, held, or_, t, nh);
+        for (int i = 0; i < HPT; ++i) mb[i] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const int h = t + i * STE_THREADS;
+        const float f0[2] = {as_f(rg[i].x), as_f(rg[i].y)}, f1[2] = {as_f(rg[i].z), as_f(rg[i].w)};
+        uint32_t w0 = T::pack(f0), w1 = T::pack(f1);
+        const uint32_t m2 = mb[i] | (mb[i] << 15);
+        w0 &= ~__builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, m2 << 15) >> (short)15);
+        w1 &= ~__builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, m2 << 13) >> (short)15);
+        if (h < nh) st8<NTS>(&or_[h], make_uint2(w0, w1));
     }
 }
 

@@ -49,13 +49,10 @@ inline int64_t largest_rows(const RowArgs& a) {
     }
     return big;
 }
-inline int64_t largest_rows(const SteMore& m, int64_t rows) {
-    if (!m.n) return rows;
-    int64_t big = m.rows0;
-    for (int i = 0; i < m.n; ++i) {
-        const int64_t end = i + 1 < m.n ? m.t[i + 1].row_begin : rows;
-        if (end - m.t[i].row_begin > big) big = end - m.t[i].row_begin;
-    }
+inline int64_t largest_rows(const SteLaunch& L) {
+    int64_t big = 0;
+    for (int i = 0; i < L.n; ++i)
+        if (L.t[i].rows > big) big = L.t[i].rows;
     return big;
 }
 
@@ -143,25 +140,40 @@ template <int DT> FQ_HIDDEN int launch_rowwise(bool asym, bool fast, RowArgs a, 
 // Sym under CUDA-autocast arithmetic (16-bit tensors only): wide = fp32 output, else rounded once to the tensor dtype
 template <int DT> FQ_HIDDEN int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t wsb, hipStream_t st);
 template <int DT> FQ_HIDDEN int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
-template <int DT>
-FQ_HIDDEN int launch_ste_mask(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                              const uint64_t* mask, hipStream_t st, const SteMore* more = nullptr);
-// STE backward of a fp32-result forward: g is fp32, gx has the (16-bit) dtype DT; mask in the wide forward's layout
-template <int DT>
-FQ_HIDDEN int launch_ste_mask_wide(const void* g, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                                   const uint64_t* mask, hipStream_t st, const SteMore* more = nullptr);
+// STE backward from (bounds, mask) for the L.n tensors of one launch (g / gx / bounds / mask / rows filled in by the caller;
+// blk_begin / inplace are set here)
+template <int DT> FQ_HIDDEN int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st);
+// the same behind a fp32-result forward: the g are fp32, the gx have the (16-bit) dtype DT
+template <int DT> FQ_HIDDEN int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st);
 template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);
 template <int DT>
 FQ_HIDDEN int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st);
-// words (uint64) of STE mask per row; 0 if the shape is not served by the mask path
+// words (uint64) of STE mask per row -- a plain bitmap, one bit per element, rows padded to 8 bytes; 0 if the shape is not
+// served by the mask path (the recording kernels are the register-resident ones: whole 16-byte vectors, rows that fit)
 inline int64_t mask_row_words(int64_t cols, int esize) {
     const int epv = 16 / esize;
     if (cols <= 0 || cols % epv) return 0;
     const int64_t nvec = cols / epv;
     if (nvec > REG_MAX_VEC) return 0;
-    return (nvec + 63) / 64 * epv;
+    return (cols + 63) / 64;
+}
+// bits of an fp16-representable float as IEEE half (host side; v has been through host_rb)
+inline uint32_t half_bits(float v) {
+    const uint32_t x = f2u(v), sign = (x >> 16) & 0x8000u, a = x & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return sign | 0x7E00u;
+    if (a == 0x7F800000u) return sign | 0x7C00u;
+    if (a < 0x38800000u) return sign | (uint32_t)__builtin_rintf(u2f(a) / 5.9604644775390625e-08f);  // subnormal: multiples of 2^-24
+    return sign | (((a >> 23) - 112u) << 10) | ((a >> 13) & 0x3FFu);
+}
+// Integer form of the STE predicate for 16-bit tensors (fq_kernels.h ste_flags16_*): applicable when lo == -hi and hi >= 0
+// (|x| >= hi as an unsigned compare of the magnitude bits); lo / hi already rounded to the dtype.  0 = compare as floats.
+inline uint32_t ste_clip_key(float lo, float hi, int dtype) {
+    if (dtype == FQ_DTYPE_F32 || !(lo == -hi) || !(hi >= 0.0f)) return 0;
+    const uint32_t t = dtype == FQ_DTYPE_BF16 ? (f2u(hi) >> 16) & 0x7FFFu : half_bits(hi) & 0x7FFFu;  // <= 0x7F80 / 0x7C00 (+inf)
+    const uint32_t k = 0x8000u - t;
+    return k | (k << 16);
 }
 template <int DT>
 FQ_HIDDEN int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi,

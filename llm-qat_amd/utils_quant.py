@@ -541,9 +541,11 @@ class QuantizeLinear(nn.Linear):
         pre = self.__dict__.pop("_fq_prefetch", None)
         if pre is not None and pre[0] == self._prefetch_key():
             return pre[1]  # the leader of this sibling group quantized this weight in its own launch
-        if not _WEIGHT_CACHE or not w.is_cuda:
-            return _SymQuantizerWeight.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         ac = ops.autocast_active(w)
+        if not _WEIGHT_CACHE or not w.is_cuda or (ac and not ops.autocast_narrow_ok(w)):
+            # (an fp16 weight inside autocast(bf16), or the reverse, gets the reference's fp32 result and an fp32 gradient:
+            # the plain node handles both dtypes; the cache's node works in the weight's dtype only)
+            return _SymQuantizerWeight.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
         key = self._wcache_key()
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:
@@ -554,7 +556,7 @@ class QuantizeLinear(nn.Linear):
             rc = ops.rows_cols(tuple(w.shape), self.weight_layerwise)
             bounds = mask = None
             if ac:  # autocast arithmetic, result rounded once to the weight dtype (see _SymQuantizerOperand)
-                y, side, rows, _, got = ops.sym_forward_autocast(w, self.w_bits, self.weight_layerwise, wide=not ops.autocast_narrow_ok(w),
+                y, side, rows, _, got = ops.sym_forward_autocast(w, self.w_bits, self.weight_layerwise, wide=False,
                                                                  train=None if _BACKWARD_MODE == "plain" else _BACKWARD_MODE)
                 if got == "mask":
                     bounds, mask = side[: rows * 8].view(torch.float32).view(rows, 2), side[rows * 8:]

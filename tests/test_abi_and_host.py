@@ -64,9 +64,9 @@ def test_argument_validation_without_gpu():
     assert L.fq_rowwise_workspace_bytes(1, 4096 * 11008, 1) == 8
     assert L.fq_rowwise_workspace_bytes(3, 40000, 0) == 24
     # STE mask: 1 bit per element, rounded up to whole 64-vector groups; 0 = shape not served
-    assert L.fq_ste_mask_bytes(4096, 11008, 1) == 4096 * 22 * 8 * 8          # 1376 vectors -> 22 groups x 8 words
+    assert L.fq_ste_mask_bytes(4096, 11008, 1) == 4096 * 172 * 8             # a plain bitmap: ceil(11008 / 64) = 172 words per row
     assert L.fq_ste_mask_bytes(2048, 4096, 1) == 2048 * 4096 // 8
-    assert L.fq_ste_mask_bytes(4, 100, 1) == 0 and L.fq_ste_mask_bytes(4, 100, 0) == 4 * 1 * 4 * 8
+    assert L.fq_ste_mask_bytes(4, 100, 1) == 0 and L.fq_ste_mask_bytes(4, 100, 0) == 4 * 2 * 8    # fp32: 25 vectors, 100 bits -> 2 words
     assert L.fq_ste_mask_bytes(1, 4096 * 11008, 1) == 0
     assert L.fq_sym_fwd_train(p, p + 16, 1, 8, 4, 1, 0, -2.0, 2.0, None, None, 0, None) == -4
     assert L.fq_ste_bwd_mask(p, p + 16, 1, 100, -2.0, 2.0, p, p, 64, 1, None) == -8

@@ -734,6 +734,87 @@ def test_wide_result_mask_path_vs_oracle(ops, dtype):
     assert rc == _lib.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_ste_mask_is_the_documented_row_bitmap(ops, dtype):
+    """ABI 3 (include/llmqat_fakequant.h): the STE mask is a plain bitmap per row -- bit j%8 of byte j/8 of row r (row stride
+    8 * ceil(cols/64) bytes) = the reference's predicate `x >= hi || x <= lo` (utils_quant.py:85-86) for element j -- written
+    for every row whose recorded bounds do not prove that nothing clips, by EVERY producer (Sym / Asym training forward, the
+    autocast forward with a 16-bit or an fp32 result, the pair launch, the scale pre-pass), and every consumer reads it:
+    a mask written by the fp32-result forward serves fq_ste_bwd_mask on a cast gradient, a 16-bit forward's serves
+    fq_ste_bwd_mask_wide.  The predicate comes from the oracle's STE (gradient of ones == 0)."""
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    code = {"bf16": _lib.DTYPE_BF16, "fp16": _lib.DTYPE_F16, "fp32": _lib.DTYPE_F32}[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(79)
+    inf = float("inf")
+    clips = ((-2.0, 2.0), (-0.5, 0.75), (-0.3009, 0.3009), (-inf, inf), (-0.0, 0.0), (-1e-3, 1e-3))
+    shapes = ((6, 4), (5, 12), (5, 8), (4, 264), (5, 520), (4, 4096), (4, 11008)) if dtype == "fp32" else ((5, 8), (6, 24), (4, 264), (5, 520), (4, 4096), (4, 11008))
+
+    def expected(x_np, rows, cols, lo, hi):
+        ones = np_from(torch.ones(rows, cols, dtype=TD[dtype]))
+        gx = O.ste_bwd(ones, x_np, lo, hi, dtype).reshape(rows, cols)
+        flags = (to_f32(gx, dtype) == 0).astype(np.uint8)
+        return np.packbits(flags, axis=1, bitorder="little")           # [rows, ceil(cols / 8)]
+
+    def check(side, rows, cols, x_np, lo, hi, what):
+        stride = 8 * ((cols + 63) // 64)
+        assert side.numel() == rows * 8 + rows * stride
+        b = side[: rows * 8].view(torch.float32).view(rows, 2).cpu().numpy()
+        m = side[rows * 8:].cpu().numpy().reshape(rows, stride)[:, : (cols + 7) // 8]
+        want = expected(x_np, rows, cols, lo, hi)
+        lo_r, hi_r = (float(torch.tensor(v).to(TD[dtype]).float()) for v in (lo, hi))     # the comparison runs in the tensor dtype
+        written = ~((b[:, 0] < hi_r) & (b[:, 1] > lo_r))
+        assert written.any(), what
+        assert (m[written] == want[written]).all(), f"{what}: bitmap differs in rows {np.argwhere((m != want).any(1) & written).ravel().tolist()}"
+        assert (want[~written] == 0).all(), f"{what}: a row the bounds call safe has clipped elements"
+
+    for rows, cols in shapes:
+        x_np, x = make_input(rng, (rows, cols), dtype, "mixed")
+        x[0] = x[0] * 0.01                                                               # a row the standard clip cannot reach
+        x[1, cols // 2] = float("nan")
+        x[2, 0], x[2, cols - 1] = 2.0, -2.0
+        x[3, cols // 3], x[3, 1] = inf, -inf
+        x_np = np_from(x)
+        mb = L.fq_ste_mask_bytes(rows, cols, code)
+        assert mb == rows * 8 * ((cols + 63) // 64)
+        for lo, hi in clips:
+            for kind in ("sym", "asym"):
+                side = torch.zeros(rows * 8 + mb, dtype=torch.uint8, device="cuda")
+                y = torch.empty_like(x)
+                fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
+                _lib.check(fn(x.data_ptr(), y.data_ptr(), rows, cols, 8, code, 0, lo, hi, side.data_ptr(), side.data_ptr() + rows * 8, mb, st), kind)
+                check(side, rows, cols, x_np, lo, hi, f"{kind}_fwd_train {dtype} {(rows, cols)} clip=({lo},{hi})")
+            # the scale pre-pass records the same side buffer
+            side = torch.zeros(rows * 8 + mb, dtype=torch.uint8, device="cuda")
+            sc = torch.empty(rows, 2, device="cuda")
+            _lib.check(L.fq_sym_row_scales(x.data_ptr(), sc.data_ptr(), rows, cols, 8, code, 0, 0, lo, hi, side.data_ptr(), side.data_ptr() + rows * 8, mb, st), "scales")
+            check(side, rows, cols, x_np, lo, hi, f"fq_sym_row_scales {dtype} {(rows, cols)} clip=({lo},{hi})")
+            if dtype == "fp32":
+                continue
+            g32 = torch.randn(rows, cols, device="cuda")
+            g16 = g32.to(TD[dtype])
+            want_g = O.ste_bwd(np_from(g16), x_np, lo, hi, dtype)
+            sides = {}
+            for wide in (0, 1):
+                side = torch.zeros(rows * 8 + mb, dtype=torch.uint8, device="cuda")
+                y = torch.empty(rows, cols, device="cuda", dtype=torch.float32 if wide else TD[dtype])
+                rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), rows, cols, 8, code, wide, lo, hi, side.data_ptr(), side.data_ptr() + rows * 8, mb, None, 0, st)
+                _lib.check(rc, "autocast fwd")
+                check(side, rows, cols, x_np, lo, hi, f"fq_sym_fwd_autocast wide={wide} {dtype} {(rows, cols)} clip=({lo},{hi})")
+                sides[wide] = side
+            # cross-consumption: any consumer reads any producer's mask
+            for wide_fwd in (0, 1):
+                sd = sides[wide_fwd]
+                gx = torch.empty_like(g16)
+                _lib.check(L.fq_ste_bwd_mask(g16.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sd.data_ptr(), sd.data_ptr() + rows * 8, mb, code, st), "bwd")
+                assert bits_equal(np_from(gx), want_g, dtype), f"narrow backward on a wide={wide_fwd} forward's mask, {(rows, cols)} clip=({lo},{hi})"
+                gx = torch.empty_like(g16)
+                _lib.check(L.fq_ste_bwd_mask_wide(g32.data_ptr(), gx.data_ptr(), rows, sd.data_ptr(), sd.data_ptr() + rows * 8, None, None, 0, None, None,
+                                                  cols, lo, hi, code, st), "bwd wide")
+                assert bits_equal(np_from(gx), want_g, dtype), f"wide backward on a wide={wide_fwd} forward's mask, {(rows, cols)} clip=({lo},{hi})"
+
+
 def test_tensors_beyond_2_31_elements(ops):
     """64-bit indexing everywhere: a layerwise row of 2^31 + 4096 elements (two-pass kernels, plain STE) and a row-wise
     tensor of 2.1e9 elements (register kernels + mask backward), against ATen on the same GPU."""

@@ -542,6 +542,49 @@ template <int DT> __device__ __forceinline__ void minmax_acc(MinMax& a, uint32_t
 }
 __device__ __forceinline__ bool absbits_is_nan(uint32_t fp32_abs_bits) { return fp32_abs_bits > 0x7F800000u; }
 
+// ---- AsymQuantizer's row min and max for 16-bit tensors, on the raw bits -------------------------------------------------
+// key = bits ^ (negative ? 0xFFFF : 0x8000) orders every bf16 / fp16 value as an unsigned 16-bit integer (-0 below +0, as
+// v_min_f32 / v_max_f32 do; positive NaNs above +inf, negative NaNs below -inf), so min and max of both halves of a dword cost
+// v_pk_ashrrev_i16 + v_bitop3 (or + xor) + v_pk_max_u16 + v_pk_min_u16: 2 VALU ops per element instead of 4 (unpack, v_max,
+// v_min and the packed |x| max that only served to detect NaN), and ONE cross-lane reduction instead of three: the lane's max
+// key and its inverted min key travel as the two halves of one dword under v_pk_max_u16.
+struct OpPkMaxU16 {
+    __device__ static __forceinline__ uint32_t f(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+    }
+};
+struct MinMaxKeys {
+    uint32_t kmx = 0u, kmn = 0xFFFFFFFFu;  // running max / min key of both halves
+    __device__ __forceinline__ void acc(uint32_t w) {
+        typedef short s16x2_t __attribute__((ext_vector_type(2)));
+        const uint32_t neg = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, w) >> (short)15);  // 0xFFFF where the half is negative
+        const uint32_t k = w ^ (neg | 0x80008000u);
+        kmx = OpPkMaxU16::f(kmx, k);
+        kmn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, kmn), __builtin_bit_cast(u16x2_t, k)));
+    }
+    // (max key << 16) | ~(min key): reduce with OpPkMaxU16
+    __device__ __forceinline__ uint32_t word() const {
+        const uint32_t mx = (kmx & 0xFFFFu) > (kmx >> 16) ? (kmx & 0xFFFFu) : (kmx >> 16);
+        const uint32_t mn = (kmn & 0xFFFFu) < (kmn >> 16) ? (kmn & 0xFFFFu) : (kmn >> 16);
+        return (mx << 16) | (~mn & 0xFFFFu);
+    }
+};
+// reduced word -> row max / min as fp32 (both NaN if the row holds a NaN: torch.max / torch.min propagate it)
+template <int DT> __device__ __forceinline__ void minmax_from_keys(uint32_t word, float& mx, float& mn) {
+    static_assert(Ty<DT>::ESIZE == 2, "16-bit tensors");
+    constexpr uint32_t INF = DT == BF16 ? 0x7F80u : 0x7C00u;
+    const uint32_t kx = word >> 16, kn = ~word & 0xFFFFu;
+    if (kx > (INF | 0x8000u) || kn < (~(INF | 0x8000u) & 0xFFFFu)) {
+        mx = mn = as_f(0x7FC00000u);
+        return;
+    }
+    const uint32_t bx = kx >= 0x8000u ? kx ^ 0x8000u : ~kx & 0xFFFFu, bn = kn >= 0x8000u ? kn ^ 0x8000u : ~kn & 0xFFFFu;
+    float f[2];
+    Ty<DT>::unpack(bx | (bn << 16), f);
+    mx = f[0];
+    mn = f[1];
+}
+
 // STE mask on one dword (utils_quant.py:85-86): zero where x >= hi or x <= lo; NaN x passes
 template <int DT> __device__ __forceinline__ uint32_t ste_dword(uint32_t g, uint32_t x, float lo, float hi) {
     using T = Ty<DT>;

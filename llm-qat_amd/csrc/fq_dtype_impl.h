@@ -73,6 +73,7 @@ template <int DT, int AC>
 static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
     clear_stale_error();
+    seal_slots(a);
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
     } else {
@@ -149,6 +150,7 @@ template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
     clear_stale_error();
+    seal_slots(a);
     constexpr int EPV = 16 / T::ESIZE;
     const bool pair = a.n_more > 0;  // several tensors in one launch: register kernels only
     const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u);

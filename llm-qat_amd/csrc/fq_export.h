@@ -113,24 +113,37 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
             a.scales[2 * row + 1] = sr.t2;
         }
     } else {
-        MinMax mm;
-        {
-            float f0[T::EPD];
-            T::unpack(r[0].x, f0);
-            mm.mx = mm.mn = f0[0];
-            mm.absacc = 0;
-        }
+        float mx, mn;
+        if constexpr (T::ESIZE == 2) {  // min and max on the raw bits (order-preserving 16-bit keys), one reduction
+            MinMaxKeys mk;
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            minmax_acc<DT>(mm, r[i].x);
-            minmax_acc<DT>(mm, r[i].y);
-            minmax_acc<DT>(mm, r[i].z);
-            minmax_acc<DT>(mm, r[i].w);
+            for (int i = 0; i < VPT; ++i) {
+                mk.acc(r[i].x);
+                mk.acc(r[i].y);
+                mk.acc(r[i].z);
+                mk.acc(r[i].w);
+            }
+            minmax_from_keys<DT>(block_reduce<OpPkMaxU16, NW>(mk.word(), red[0]), mx, mn);
+        } else {
+            MinMax mm;
+            {
+                float f0[T::EPD];
+                T::unpack(r[0].x, f0);
+                mm.mx = mm.mn = f0[0];
+                mm.absacc = 0;
+            }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                minmax_acc<DT>(mm, r[i].x);
+                minmax_acc<DT>(mm, r[i].y);
+                minmax_acc<DT>(mm, r[i].z);
+                minmax_acc<DT>(mm, r[i].w);
+            }
+            uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
+            block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
+            mx = as_f(umx), mn = as_f(umn);
+            if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
         }
-        uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
-        block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
-        float mx = as_f(umx), mn = as_f(umn);
-        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);
         ar = asym_row<DT>(mx, mn, a.asym);
         ub = mx;
         lb = mn;
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         return;  // the scale pre-pass: nothing elementwise to do
     }
     char* brow = (char*)a.bins + row * a.row_bytes;
-    uint32_t nbad = 0;  // wave-uniform
+    uint32_t nbad = 0;  // per lane; summed over the wave after the loop
     uint32_t pk[VPT][4] = {};  // this lane's packed bins per slot (EPV * container bits / 32 dwords used)
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
                 const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
                 bool bad;
                 q[e] = sat_bin(b, a.cmin, a.cmax, bad);
-                nbad += (uint32_t)__popcll(__ballot(bad && v < nvec));
+                nbad += (bad && v < nvec) ? 1u : 0u;  // (a ballot + popcount per element made these rows ~10x slower than the others)
             }
         }
         // pack this slot's bins; the stores follow the loop (lanes trade packed dwords so that each store is 16 bytes)
@@ -273,8 +286,12 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         if (!count) {
             if (t == 0) a.overflow[row] = 0;
         } else if constexpr (NW == 1) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nbad += (uint32_t)__shfl_xor((int)nbad, o, 64);
             if (t == 0) a.overflow[row] = (int32_t)nbad;
         } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nbad += (uint32_t)__shfl_xor((int)nbad, o, 64);
             if ((t & 63) == 0) cnt_lds[t >> 6] = nbad;
             __syncthreads();  // `count` is block-uniform
             if (t == 0) {

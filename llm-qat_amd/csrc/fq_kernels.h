@@ -134,6 +134,10 @@ template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// (Which tensor of a multi-tensor launch a row belongs to is decided by a short branch chain in the kernels below: a
+// branch-free variant -- all slots' kernarg fields loaded up front, chosen with selects, as the mask backward does -- measured
+// 2-4 % SLOWER on the [2048,4096] forward launches, profiles/r03_ab_forward_pick_tensor.txt: the single-tensor launch pays one
+// compare today.)
 // ------------------------------------------------------------------------------------
 // Register-resident row kernel.
 //   nvec = cols / elements-per-16B must satisfy nvec <= TPR * VPT.
@@ -226,24 +230,37 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
             }
         }
     } else {
-        MinMax mm;
-        {
-            float f0[T::EPD];
-            T::unpack(r[0].x, f0);
-            mm.mx = mm.mn = f0[0];
-            mm.absacc = 0;
-        }
+        float mx, mn;
+        if constexpr (T::ESIZE == 2) {  // min and max on the raw bits (order-preserving 16-bit keys), one reduction
+            MinMaxKeys mk;
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            minmax_acc<DT>(mm, r[i].x);
-            minmax_acc<DT>(mm, r[i].y);
-            minmax_acc<DT>(mm, r[i].z);
-            minmax_acc<DT>(mm, r[i].w);
+            for (int i = 0; i < VPT; ++i) {
+                mk.acc(r[i].x);
+                mk.acc(r[i].y);
+                mk.acc(r[i].z);
+                mk.acc(r[i].w);
+            }
+            minmax_from_keys<DT>(block_reduce<OpPkMaxU16, NW>(mk.word(), red[0]), mx, mn);
+        } else {
+            MinMax mm;
+            {
+                float f0[T::EPD];
+                T::unpack(r[0].x, f0);
+                mm.mx = mm.mn = f0[0];
+                mm.absacc = 0;
+            }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                minmax_acc<DT>(mm, r[i].x);
+                minmax_acc<DT>(mm, r[i].y);
+                minmax_acc<DT>(mm, r[i].z);
+                minmax_acc<DT>(mm, r[i].w);
+            }
+            uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
+            block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
+            mx = as_f(umx), mn = as_f(umn);
+            if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
         }
-        uint32_t nb = T::absmax_finish(mm.absacc), umx = as_u(mm.mx), umn = as_u(mm.mn);
-        block_reduce3<OpMaxU, OpMaxF, OpMinF, NW>(nb, umx, umn, red);
-        float mx = as_f(umx), mn = as_f(umn);
-        if (absbits_is_nan(nb)) mx = mn = as_f(0x7FC00000u);  // torch.max/min propagate NaN
         ar = asym_row<DT>(mx, mn, a.asym);
         ub = mx;
         lb = mn;

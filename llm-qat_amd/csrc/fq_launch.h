@@ -35,6 +35,13 @@ inline bool more_aligned(const RowArgs& a, uintptr_t xmask, uintptr_t ymask) {
         if ((reinterpret_cast<uintptr_t>(a.more[i].x) & xmask) || (reinterpret_cast<uintptr_t>(a.more[i].y) & ymask)) return false;
     return true;
 }
+// the kernels compare a row against every slot's first row (pick_tensor): unused slots must never match
+inline void seal_slots(RowArgs& a) {
+    for (int i = a.n_more; i < MAX_MORE; ++i) {
+        a.more[i] = TensorSlot{};
+        a.more[i].row_begin = INT64_MAX;
+    }
+}
 inline bool any_mask(const RowArgs& a) {
     bool m = a.mask != nullptr;
     for (int i = 0; i < a.n_more; ++i) m = m || a.more[i].mask;

@@ -58,6 +58,23 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ in,
     }
 }
 
+// read R vectors, write 1 (the export kernels' byte ratio: int8 = 2:1, int4 = 4:1): what does the device sustain?
+template <int R, bool NT>
+__global__ __launch_bounds__(256) void shrink_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nout) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t oc = o < nout ? o : nout - 1;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {   // R input planes, each read fully coalesced
+        const uint4 v = NT ? ld_nt(&in[(int64_t)k * nout + oc]) : in[(int64_t)k * nout + oc];
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+    }
+    if (o < nout) {
+        if constexpr (NT) st_nt(&out[o], acc);
+        else out[o] = acc;
+    }
+}
+
 // grid-stride copy: fixed grid, each block walks tiles
 template <int UNR, bool NT>
 __global__ __launch_bounds__(256) void copy_gs_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nvec) {
@@ -176,6 +193,7 @@ static void launch_sym(const void* x, void* y, float* bounds, int64_t rows, int6
     a.x = x; a.y = y; a.idx = nullptr; a.scale = nullptr; a.bounds = bounds; a.rows = rows; a.rows0 = rows; a.cols = cols;
     a.sym.qmax = (float)((1 << (bits - 1)) - 1);
     a.sym.c6 = 9.98377799987793e-07f;
+    for (int i = 0; i < MAX_MORE; ++i) a.more[i].row_begin = INT64_MAX;  // single tensor: no slot may match (pick_tensor)
     const int64_t grid = TPR == 64 ? (rows + 3) / 4 : rows;
     hipLaunchKernelGGL((row_reg_kernel<BF16, TPR, VPT, false, FAST, NTL, NTS>), dim3((unsigned)grid), dim3(TPR == 64 ? 256 : TPR), 0, 0, a);
 }
@@ -248,6 +266,13 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(big));
     }
+#define SHRINK(R)                                                                                                                   \
+    report("shrink<read " #R " : write 1, NT>", (1.0 + 1.0 / R) * bytes, time_it([&](int i) {                                      \
+               hipLaunchKernelGGL((shrink_kernel<R, true>), dim3((unsigned)((nvec / R + 255) / 256)), dim3(256), 0, 0,             \
+                                  (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec / R);                                        \
+           }, IT));
+    SHRINK(2) SHRINK(4)
+    if (argc > 3 && std::string(argv[3]) == "ceilings") return 0;
     uint32_t* sink;
     CK(hipMalloc(&sink, 64));
     report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {

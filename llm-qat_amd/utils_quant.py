@@ -12,6 +12,7 @@ so `models/modeling_llama_quant.py` (which imports them by name, :51) and everyt
 single-pass HIP kernels for gfx950 (see INTEGRATION.md for the one-line switch).
 """
 import os
+import sys
 import threading
 import weakref
 
@@ -121,6 +122,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "compiled":
             input, clip_val = ctx.saved_tensors
             return compiled.fake_quant_bwd(grad_output, input, clip_val), None, None, None
+        inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
         _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
             lo, hi = ctx.clip
@@ -129,11 +131,12 @@ class _FakeQuantFunction(torch.autograd.Function):
             return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.grad_dtype), None, None, None
         if ctx.grad_dtype is not None and grad_output.dtype != ctx.grad_dtype:
             grad_output = grad_output.to(ctx.grad_dtype)  # autocast: fp32 grad of the fp32 output; zeroing commutes with the cast
+            inplace = ctx.fq_inplace and _INPLACE_WGRAD   # a fresh tensor of our own
         if ctx.fq_mode == "mask":
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
             (side,) = ctx.saved_tensors
-            return ops.train_backward(grad_output, side, rows, cols, lo, hi, inplace=ctx.fq_inplace and _INPLACE_WGRAD), None, None, None
+            return ops.train_backward(grad_output, side, rows, cols, lo, hi, inplace=inplace), None, None, None
         saved = ctx.saved_tensors  # reference :83 / :158: (input, clip_val) [+ the row bounds in "bounds" mode]
         input, clip_val = saved[0], saved[1]
         lo, hi = _clip_pair(clip_val)
@@ -233,6 +236,82 @@ _INPLACE_WGRAD = os.environ.get("LLMQAT_AMD_INPLACE_WEIGHT_GRAD", "1") != "0"
 def inplace_weight_grad(flag=True):
     global _INPLACE_WGRAD
     _INPLACE_WGRAD = bool(flag)
+
+
+#    This deviates from PyTorch's rule for Function.backward ("never modify grad_outputs in place"), so it is GUARDED at run
+#    time: the gradient is masked where it stands only if this node provably holds the only handle on it --
+#      * it covers its whole storage (contiguous, offset 0, storage size == tensor size): never a slice of somebody's buffer;
+#      * no other Python object refers to it (sys.getrefcount against a calibrated baseline: a tensor hook that stashes the
+#        gradient, or one that substitutes its own tensor, raises the count) and no other C++ holder does (Tensor._use_count();
+#        if it is a view -- F.linear's wgrad arrives as a view of a temporary -- the base has no other holder either);
+#      * anomaly mode is off (it keeps gradients for its diagnostics).
+#    Anything else takes the copying launch: same values, the reference's data flow (tests/test_gpu_features.py
+#    ::test_inplace_weight_gradient_is_guarded).  What a hook is handed is the gradient BEFORE this node's mask, as with the
+#    reference's clone -- hooks run before the node.
+_ref_base = {}
+
+
+def _grad_counts(g):
+    return sys.getrefcount(g), g._use_count()
+
+
+def _base_counts(g):
+    b = g._base
+    return sys.getrefcount(b), b._use_count()
+
+
+def _calibrate_grad_counts():
+    """Reference counts of a gradient as it arrives in a backward written like the ones below, with nobody else holding it
+    ("named": backward(ctx, gw, gx); "star": backward(ctx, *grads), read by index).  Run once at import on tiny CPU tensors,
+    through the same decorators, F.linear producing the gradient as in QuantizeLinear."""
+    class _Named(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, x):
+            return w * 1.0, x * 1.0
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, gw, gx):
+            _ref_base["named"] = _grad_counts(gw)
+            return gw, gx
+
+    class _Star(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, x):
+            return w * 1.0, x * 1.0
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, *grads):
+            _ref_base["star"] = _grad_counts(grads[0])
+            return grads
+
+    _ref_base["base"] = _base_counts(torch.zeros(2, 4).view(4, 2))   # a view of a temporary nobody else holds
+    with torch.inference_mode(False), torch.enable_grad():
+        for fn in (_Named, _Star):
+            w = torch.zeros(2, 4, requires_grad=True)
+            x = torch.zeros(3, 4, requires_grad=True)
+            wq, xq = fn.apply(w, x)
+            nn.functional.linear(xq, wq).sum().backward()
+
+
+def _owns_storage(g):
+    """the tensor IS its storage: contiguous, offset 0, nothing before or after it in the allocation"""
+    return g.is_contiguous() and g.storage_offset() == 0 and g.untyped_storage().nbytes() == g.numel() * g.element_size()
+
+
+def _inplace_ok(g, style="named"):
+    """may this backward mask grad_output `g` where it stands?  Called directly from the backward with the argument itself
+    (`_inplace_ok(gw)` / `_inplace_ok(grads[i], "star")`) so that the reference count compares with the calibration."""
+    base = _ref_base.get(style)
+    if base is None or not _owns_storage(g) or torch.is_anomaly_enabled():
+        return False
+    if sys.getrefcount(g) > base[0] or g._use_count() > base[1]:
+        return False
+    if g._base is None:
+        return True
+    bc, bb = _base_counts(g), _ref_base["base"]  # F.linear's wgrad arrives as a view of a temporary: fine if nobody else can reach it
+    return bc[0] <= bb[0] and bc[1] <= bb[1]
 
 
 _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every call (:198, :245)
@@ -364,6 +443,7 @@ class _PairNode(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gw, gx):
+        inplace_w = ctx.inplace_w and _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
         _bwd_epoch[0] += 1
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lo, hi = ctx.clip
@@ -374,11 +454,14 @@ class _PairNode(torch.autograd.Function):
                 return None, None, None, None, None
             ow, ox = ops.pair_backward_wide(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
             return ow, ox, None, None, None
-        gw = gw.to(ctx.dtype) if (need_w and gw is not None and gw.dtype != ctx.dtype) else (gw if need_w else None)
+        if need_w and gw is not None and gw.dtype != ctx.dtype:
+            gw, inplace_w = gw.to(ctx.dtype), ctx.inplace_w and _INPLACE_WGRAD   # a fresh tensor of our own
+        elif not need_w:
+            gw = None
         gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
         if gw is None and gx is None:
             return None, None, None, None, None
-        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=ctx.inplace_w and _INPLACE_WGRAD)
+        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=inplace_w)
         return ow, ox, None, None, None
 
 
@@ -389,7 +472,10 @@ class _PairNode(torch.autograd.Function):
 #    finds its activation already quantized by another module registers with that module, and is served from the next
 #    forward on.  A prefetched weight is used only if the weight is still the very tensor (identity, version, storage) it
 #    was computed from, in the same grad / autocast / backward mode, with no fake-quant backward in between.
-_GROUP = os.environ.get("LLMQAT_AMD_GROUP_SIBLINGS", "1") != "0"
+#    OPT-IN since round 3 (LLMQAT_AMD_GROUP_SIBLINGS=1 / group_siblings(True)): measured on the two-layer 7B-sized step it buys
+#    nothing end to end (16.03 vs 16.02 ms; checkpointing 20.35 vs 20.49 ms, profiles/r02_model_step_bench_autocast.json -- the
+#    GEMMs hide the launch count), so the default path carries no learned, stateful dispatch; operand pairing (point 3) stays.
+_GROUP = os.environ.get("LLMQAT_AMD_GROUP_SIBLINGS", "0") == "1"
 _MAX_FOLLOWERS = 2
 
 
@@ -416,15 +502,19 @@ class _MultiNode(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
+        # tensor 1 is the shared input; the others are weights, whose gradients may be masked where they stand (guarded)
+        inplace = [_INPLACE_WGRAD and i != 1 and grads[i] is not None and _inplace_ok(grads[i], "star") for i in range(len(grads))]
         _bwd_epoch[0] += 1
         lo, hi = ctx.clip
         gs = []
-        for g, need in zip(grads, ctx.needs_input_grad[2:]):
-            if g is None or not need:
+        for i, need in enumerate(ctx.needs_input_grad[2:]):
+            if grads[i] is None or not need:
                 gs.append(None)
+            elif grads[i].dtype == ctx.dtype:
+                gs.append(grads[i])
             else:
-                gs.append(g if g.dtype == ctx.dtype else g.to(ctx.dtype))
-        inplace = [_INPLACE_WGRAD and i != 1 for i in range(len(gs))]  # tensor 1 is the shared input; the others are weights
+                gs.append(grads[i].to(ctx.dtype))
+                inplace[i] = _INPLACE_WGRAD and i != 1   # a fresh tensor of our own
         outs = ops.multi_backward(gs, list(ctx.saved_tensors), ctx.rows, ctx.cols, lo, hi, inplace=inplace)
         return (None, None) + tuple(outs)
 
@@ -469,11 +559,12 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
+        inplace = _INPLACE_WGRAD and _inplace_ok(grad_output)
         lo, hi = ctx.clip
         weight, row_bounds, ste_mask = ctx.saved_tensors
         if ste_mask is not None:
             rows, cols = ctx.rows_cols
-            return ops.ste_backward_mask(grad_output, lo, hi, row_bounds, ste_mask, rows, cols, inplace=_INPLACE_WGRAD), None, None
+            return ops.ste_backward_mask(grad_output, lo, hi, row_bounds, ste_mask, rows, cols, inplace=inplace), None, None
         bounds = row_bounds if grad_output.is_contiguous() and weight.is_contiguous() else None
         return ops.ste_backward(grad_output, weight, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols), None, None
 
@@ -736,3 +827,9 @@ class QuantizeLinear(nn.Linear):
         if self.bias is not None:
             out += self.bias.view(1, -1).expand_as(out)
         return out
+
+
+try:
+    _calibrate_grad_counts()
+except Exception:  # noqa: BLE001 -- without a baseline _inplace_ok() answers False: every gradient takes the copying launch
+    _ref_base.clear()

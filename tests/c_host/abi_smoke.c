@@ -15,6 +15,8 @@
 
 int fqo_sym_fwd(const void*, void*, int32_t*, float*, int64_t, int64_t, int, int, int);
 int fqo_ste_bwd(const void*, const void*, void*, int64_t, float, float, int);
+int fqo_export(const void* x, void* bins, float* scales, int32_t* overflow, int64_t rows, int64_t cols, int bits, int container, int dt, int sem,
+               int asym, int autocast);
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 2; } } while (0)
 #define FQ(x) do { int rc_ = (x); if (rc_ != FQ_OK) { fprintf(stderr, "%s:%d rc=%d %s\n", __FILE__, __LINE__, rc_, fq_last_error()); return 3; } } while (0)
@@ -61,6 +63,107 @@ int main(void) {
         if (memcmp(hy, oy, n * 2) || memcmp(hgx, ogx, n * 2)) { fprintf(stderr, "bits %d: mismatch vs oracle (training flow)\n", bits); return 6; }
     }
     if (fq_sym_fwd(dx, dy, rows, cols, 99, FQ_DTYPE_BF16, 0, NULL, NULL, 0, st) != FQ_ERR_BITS || !strstr(fq_last_error(), "num_bits")) return 7;
-    printf("c host ok: %lld elements x 2 bit widths x 2 data flows bit-equal to the oracle\n", (long long)n);
+
+    /* ---- ABI 2 / 3 entry points, each against the oracle ---------------------------------------------------------------- */
+    /* (a) fq_sym_fwd_multi + fq_ste_bwd_mask_multi: the tensor split in three (W4 rows 0..11, A8 rows 12..29, W4 rows 30..36) in ONE
+     *     launch each way; the first slot's gradient in place (gx == g) */
+    {
+        const int64_t r0 = 12, r1 = 18, r2 = rows - 30;
+        const int bitsv[3] = {4, 8, 4};
+        const int64_t rv[3] = {r0, r1, r2}, ov[3] = {0, r0, r0 + r1};
+        void* dgi;  /* a private copy of the first slot's gradient: masked where it stands */
+        CK(hipMalloc(&dgi, r0 * cols * 2));
+        CK(hipMemcpy(dgi, dg, r0 * cols * 2, hipMemcpyDeviceToDevice));
+        fq_fwd_tensor ft[3];
+        fq_bwd_tensor bt[3];
+        size_t moff = 0;
+        for (int i = 0; i < 3; ++i) {
+            const size_t mb = fq_ste_mask_bytes(rv[i], cols, FQ_DTYPE_BF16);
+            ft[i].x = (char*)dx + ov[i] * cols * 2; ft[i].y = (char*)dy + ov[i] * cols * 2; ft[i].rows = rv[i]; ft[i].bits = bitsv[i];
+            ft[i].row_bounds = dbounds + 2 * ov[i]; ft[i].mask = (char*)dmask + moff; ft[i].mask_bytes = mb;
+            bt[i].g = i == 0 ? dgi : (char*)dg + ov[i] * cols * 2; bt[i].gx = i == 0 ? dgi : (char*)dgx + ov[i] * cols * 2; bt[i].rows = rv[i];
+            bt[i].row_bounds = ft[i].row_bounds; bt[i].mask = ft[i].mask;
+            moff += mb;
+        }
+        if (moff > mbytes) return 8;
+        CK(hipMemsetAsync(dy, 0, n * 2, st)); CK(hipMemsetAsync(dgx, 0, n * 2, st));
+        FQ(fq_sym_fwd_multi(3, ft, cols, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, st));
+        FQ(fq_ste_bwd_mask_multi(3, bt, cols, -2.0f, 2.0f, FQ_DTYPE_BF16, 0, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hy, dy, n * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hgx, dgx, n * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hgx, dgi, r0 * cols * 2, hipMemcpyDeviceToHost));   /* slot 0's result stands in its own gradient buffer */
+        for (int i = 0; i < 3; ++i) {
+            const int64_t off = ov[i] * cols;
+            if (fqo_sym_fwd(hx + off, oy + off, NULL, NULL, rv[i], cols, bitsv[i], 1, 0)) return 4;
+        }
+        if (fqo_ste_bwd(hg, hx, ogx, n, -2.0f, 2.0f, 1)) return 4;
+        if (memcmp(hy, oy, n * 2) || memcmp(hgx, ogx, n * 2)) { fprintf(stderr, "multi-tensor launch: mismatch vs oracle\n"); return 9; }
+        CK(hipFree(dgi));
+    }
+    /* (b) fq_sym_export (int4 / int8 / int16 + scales + overflow counts) and fq_sym_row_scales */
+    {
+        const int conts[3] = {FQ_BINS_INT4, FQ_BINS_INT8, FQ_BINS_INT16};
+        void* dbins;
+        float* dsc;
+        int32_t* dov;
+        CK(hipMalloc(&dbins, n * 2)); CK(hipMalloc((void**)&dsc, rows * 8)); CK(hipMalloc((void**)&dov, rows * 4));
+        uint8_t *hb = malloc(n * 2), *ob = malloc(n * 2);
+        float *hs = malloc(rows * 8), *os = malloc(rows * 8);
+        int32_t *hov = malloc(rows * 4), *oov = malloc(rows * 4);
+        for (int bits = 4; bits <= 8; bits += 4)
+            for (int c = 0; c < 3; ++c) {
+                const size_t bb = fq_export_bins_bytes(rows, cols, conts[c]);
+                FQ(fq_sym_export(dx, dbins, dsc, dov, rows, cols, bits, conts[c], FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(hb, dbins, bb, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, dsc, rows * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hov, dov, rows * 4, hipMemcpyDeviceToHost));
+                memset(ob, 0, bb);
+                if (fqo_export(hx, ob, os, oov, rows, cols, bits, conts[c], 1, 0, 0, 0)) return 4;
+                if (memcmp(hb, ob, bb) || memcmp(hs, os, rows * 8) || memcmp(hov, oov, rows * 4)) {
+                    fprintf(stderr, "export bits %d container %d: mismatch vs oracle\n", bits, conts[c]);
+                    return 10;
+                }
+            }
+        FQ(fq_sym_row_scales(dx, dsc, rows, cols, 8, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, NULL, NULL, 0, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hs, dsc, rows * 8, hipMemcpyDeviceToHost));
+        if (memcmp(hs, os, rows * 8)) { fprintf(stderr, "fq_sym_row_scales: mismatch vs the oracle's export scales\n"); return 11; }
+        /* (c) fq_qlinear_fwd: out = fq(x) . fq(W)^T with W = rows 5..36 of the same data (32 out features), x = rows 0..4 (5 tokens),
+         *     in = 11008 (% 64 == 0): the operand tiles as staged for the MFMAs against the oracle, the product against a double sum */
+        {
+            const int64_t tok = 5, outf = 32;
+            float *dxs, *dws;
+            void *dout, *dumpx, *dumpw;
+            CK(hipMalloc((void**)&dxs, tok * 8)); CK(hipMalloc((void**)&dws, outf * 8)); CK(hipMalloc(&dout, tok * outf * 2));
+            CK(hipMalloc(&dumpx, tok * cols * 2)); CK(hipMalloc(&dumpw, outf * cols * 2));
+            const void* dw = (char*)dx + tok * cols * 2;
+            FQ(fq_sym_row_scales(dx, dxs, tok, cols, 8, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, NULL, NULL, 0, st));
+            FQ(fq_sym_row_scales(dw, dws, outf, cols, 4, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, NULL, NULL, 0, st));
+            FQ(fq_qlinear_fwd(dx, dxs, dw, dws, dout, tok, cols, outf, FQ_DTYPE_BF16, 0, dumpx, dumpw, 0, st));
+            CK(hipStreamSynchronize(st));
+            uint16_t *sx = malloc(tok * cols * 2), *sw = malloc(outf * cols * 2), *ho = malloc(tok * outf * 2);
+            CK(hipMemcpy(sx, dumpx, tok * cols * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(sw, dumpw, outf * cols * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ho, dout, tok * outf * 2, hipMemcpyDeviceToHost));
+            if (fqo_sym_fwd(hx, oy, NULL, NULL, tok, cols, 8, 1, 0) || fqo_sym_fwd(hx + tok * cols, oy + tok * cols, NULL, NULL, outf, cols, 4, 1, 0)) return 4;
+            if (memcmp(sx, oy, tok * cols * 2) || memcmp(sw, oy + tok * cols, outf * cols * 2)) { fprintf(stderr, "fq_qlinear_fwd: staged operands != oracle\n"); return 12; }
+            for (int64_t t = 0; t < tok; ++t)
+                for (int64_t o = 0; o < outf; ++o) {
+                    double acc = 0, mag = 0;
+                    for (int64_t k = 0; k < cols; ++k) {
+                        uint32_t ua = (uint32_t)oy[t * cols + k] << 16, ub = (uint32_t)oy[(tok + o) * cols + k] << 16;
+                        float fa, fb;
+                        memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+                        acc += (double)fa * fb; mag += (fa < 0 ? -(double)fa : fa) * (fb < 0 ? -(double)fb : fb);
+                    }
+                    uint32_t ur = (uint32_t)ho[t * outf + o] << 16;
+                    float fr;
+                    memcpy(&fr, &ur, 4);
+                    const double tol = (acc < 0 ? -acc : acc) / 256.0 + mag * cols / 16777216.0 + 1e-30;   /* half a bf16 ulp + fp32 accumulation */
+                    if (!(((double)fr - acc < tol) && (acc - (double)fr < tol))) { fprintf(stderr, "fq_qlinear_fwd: out[%lld][%lld] = %g, want %g\n", (long long)t, (long long)o, fr, acc); return 13; }
+                }
+        }
+    }
+    printf("c host ok: %lld elements x 2 bit widths x 2 data flows, multi-tensor launches, export x 3 containers, row scales and the fused GEMM's operands bit-equal to the oracle\n", (long long)n);
     return 0;
 }

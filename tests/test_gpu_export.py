@@ -83,6 +83,43 @@ def test_export_vs_oracle(ops, kind, dtype):
                 assert bits_equal(e.scales.cpu().numpy(), osc, "fp32"), f"{kind} {dtype} {(rows, cols)} b{bits}: scales"
 
 
+@pytest.mark.parametrize("style,shape,bits,container", [("weight", (4096, 11008), 4, "int4"), ("weight", (4096, 11008), 8, "int8"),
+                                                        ("weight", (4096, 11008), 8, "int16"), ("act", (4096, 11008), 8, "int8"),
+                                                        ("act", (2048, 4096), 4, "int4"), ("act", (2048, 11008), 8, "int8")])
+def test_export_at_metric_size_vs_oracle(ops, style, shape, bits, container):
+    """the export kernels at BASELINE.json's sizes (the tensors bench.py times): packed bytes, scales and overflow counts of
+    >= 40 sampled rows -- first, last, evenly spaced, and rows the container saturates -- bit-identical to the CPU oracle; plus
+    size-independent properties over the whole tensor (every bin inside the container, overflow == #bins the reference's
+    rounding puts outside it, dequantisation == the fake-quant forward where nothing overflowed)."""
+    rows, cols = shape
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn(shape, generator=g, device="cuda")
+    if style == "weight":
+        x *= 0.02
+    else:
+        x[torch.rand(shape, generator=g, device="cuda") < 1e-3] *= 20.0
+    x = x.bfloat16()
+    e = ops.sym_export(x, bits, False, container=container, autocast=False)
+    over = e.overflow.cpu().numpy()
+    sat_rows = np.flatnonzero(over)[:8].tolist()
+    sel = sorted(set(np.linspace(0, rows - 1, 40).astype(int).tolist() + sat_rows))
+    ob, osc, oov = O.export("sym", np_from(x[sel]), len(sel), cols, bits, container, "bf16")
+    raw = e.bins.contiguous().view(torch.uint8).reshape(rows, -1)[sel].cpu().numpy()
+    assert (raw == ob).all(), f"{(raw != ob).sum()} packed bytes differ on the sampled rows"
+    assert (over[sel] == oov).all() and bits_equal(e.scales[sel].cpu().numpy(), osc, "fp32")
+    # whole tensor: the unclamped bins of the debug forward (oracle-checked elsewhere) vs the container
+    y, idx, _ = ops.sym_quantize_debug(x, bits, False)
+    lo, hi = _crange(container, True)
+    assert torch.equal(e.unpacked(), idx.clamp(lo, hi))
+    assert torch.equal(e.overflow.long(), ((idx < lo) | (idx > hi)).sum(dim=1))
+    if container == "int8" and bits == 8:
+        assert over.sum() > 0, "bf16 8-bit rows reach the bin +128: some rows must saturate an int8 container"
+    clean = e.overflow == 0
+    assert clean.any()
+    deq = e.dequantize()
+    assert torch.equal((deq[clean].float() + 0.0), (y[clean].float() + 0.0))       # (+ 0.0: an integer bin has no -0)
+
+
 def test_export_misaligned_and_noncontiguous(ops):
     rng = np.random.default_rng(12)
     flat = torch.from_numpy(rng.standard_normal(4096 * 3 + 1).astype(np.float32)).cuda().bfloat16()

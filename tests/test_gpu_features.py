@@ -826,6 +826,121 @@ def test_autocast_dtype_differs_from_tensor_dtype(pkg):
         assert torch.equal(got, want), (tdt, adt, (got.float() - want.float()).abs().max())
 
 
+@pytest.mark.parametrize("cols", [256, 11008])
+def test_weight_cache_with_autocast_dtype_mismatch_gradients(pkg, cols):
+    """weight cache ON + an fp16 weight inside autocast(bf16) (or the reverse) + weight entries beyond the
+    STE clip.  Round 2's cache took the fp32-result forward (its own mask layout) and ran the 16-bit-layout backward on it:
+    rows that clip read another row's mask bits whenever the two row strides differed (cols = 256: 8 vs 4 words; 11008: 176 vs
+    172).  Now the mismatch bypasses the cache (and every mask is the same row bitmap anyway): forward values and BOTH
+    gradients bit-identical to the cache-off path, in-place weight gradients on and off, pairing on and off."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+
+    def run(tdt, adt, cache, inplace, pairing):
+        torch.manual_seed(11)
+        lin = QuantizeLinear(cols, 64, w_bits=4, a_bits=8).cuda().to(tdt)
+        with torch.no_grad():
+            lin.weight[3, 5], lin.weight[3, cols - 1], lin.weight[40, 0], lin.weight[63, cols // 2] = 2.5, -2.0, 2.0, -7.0
+        x = (torch.randn(4, 8, cols, device="cuda") * 1.3).to(tdt).requires_grad_(True)
+        pkg.enable_weight_quant_cache(cache)
+        pkg.inplace_weight_grad(inplace)
+        pkg.pair_operands(pairing)
+        try:
+            outs = []
+            for _ in range(2):        # second pass: the cache (if it engaged) serves the weight
+                lin.weight.grad = x.grad = None
+                with torch.autocast("cuda", dtype=adt):
+                    y = lin(x)
+                y.float().square().sum().backward()
+                outs.append((y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()))
+        finally:
+            pkg.enable_weight_quant_cache(False)
+            pkg.inplace_weight_grad(True)
+            pkg.pair_operands(True)
+        return outs
+
+    for tdt, adt in ((torch.float16, torch.bfloat16), (torch.bfloat16, torch.float16), (torch.bfloat16, torch.bfloat16)):
+        base = run(tdt, adt, cache=False, inplace=False, pairing=False)
+        gw = base[0][2]
+        assert gw[3, 5] == 0 and gw[3, cols - 1] == 0 and gw[40, 0] == 0 and gw[63, cols // 2] == 0 and gw[3, 6] != 0   # the STE clip at work
+        for cache, inplace, pairing in ((True, True, True), (True, False, False), (True, True, False), (False, True, True)):
+            got = run(tdt, adt, cache, inplace, pairing)
+            for (ya, xa, wa), (yb, xb, wb) in zip(got, base):
+                assert ya.dtype == yb.dtype and torch.equal(ya, yb), (tdt, adt, cache, inplace, pairing)
+                assert torch.equal(xa, xb) and torch.equal(wa, wb), (tdt, adt, cache, inplace, pairing)
+
+
+def test_inplace_weight_gradient_is_guarded(pkg):
+    """VERDICT r02 item 10 / ADVICE: handing F.linear's wgrad on by reference (masked in place) deviates from PyTorch's "never
+    modify grad_outputs in place" rule; it is taken only when the gradient tensor owns its whole storage (no view, offset 0,
+    contiguous) and nobody can observe it: a tensor hook or retain_grad() on the quantized weight, anomaly mode, or a view into a
+    larger buffer fall back to the copy.  Gradients are identical either way; observers see the UNMASKED gradient they are entitled to."""
+    from llm_qat_amd import utils_quant as U
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(13)
+    lin = QuantizeLinear(512, 128, w_bits=4, a_bits=8).cuda().bfloat16()
+    with torch.no_grad():
+        lin.weight[7, 9] = 2.25          # a weight element beyond the clip: its gradient is masked
+    x = (torch.randn(16, 512, device="cuda") * 1.2).bfloat16().requires_grad_(True)
+
+    flags = []
+    orig_pb = U.ops.pair_backward
+
+    def pb_spy(*a, inplace_w=False, **k):
+        flags.append(bool(inplace_w))
+        return orig_pb(*a, inplace_w=inplace_w, **k)
+
+    def grads(hook=None):
+        lin.weight.grad = x.grad = None
+        seen = {}
+        orig = torch.nn.functional.linear
+
+        def spy(inp, w, b=None):          # catch the quantized weight the module hands to F.linear
+            if hook == "clone" and w.requires_grad:
+                w.register_hook(lambda g: seen.__setitem__("g", g.clone()))
+            if hook == "stash" and w.requires_grad:
+                w.register_hook(lambda g: seen.__setitem__("g", g))      # keeps the very tensor the node is about to receive
+            return orig(inp, w, b)
+        torch.nn.functional.linear = spy
+        U.ops.pair_backward = pb_spy
+        try:
+            y = lin(x)
+            y.float().square().sum().backward()
+        finally:
+            torch.nn.functional.linear = orig
+            U.ops.pair_backward = orig_pb
+        return lin.weight.grad.clone(), x.grad.clone(), seen.get("g")
+
+    pkg.inplace_weight_grad(False)
+    want_w, want_x, _ = grads()
+    assert flags == [False]
+    pkg.inplace_weight_grad(True)
+    got_w, got_x, _ = grads()
+    assert flags[-1] is True, "the guarded in-place path never engages in the plain module flow: the guard is miscalibrated on this device"
+    assert torch.equal(got_w, want_w) and torch.equal(got_x, want_x) and got_w[7, 9] == 0
+    # a hook that clones: it observes the gradient BEFORE the STE mask (as with the reference's clone): not zero at [7, 9]
+    got_w, got_x, seen = grads(hook="clone")
+    assert torch.equal(got_w, want_w) and torch.equal(got_x, want_x)
+    assert seen is not None and seen[7, 9] != 0, "the hook saw a gradient that had already been masked in place"
+    # a hook that keeps the tensor itself: somebody else holds the gradient -> the node copies, the stashed tensor stays unmasked
+    got_w, got_x, seen = grads(hook="stash")
+    assert flags[-1] is False and torch.equal(got_w, want_w) and torch.equal(got_x, want_x)
+    assert seen[7, 9] != 0, "a gradient someone else holds was modified in place"
+    # the ownership test itself
+    g = torch.randn(128, 512, device="cuda").bfloat16()
+    assert U._owns_storage(g)
+    assert not U._owns_storage(g[1:])                       # a view (storage offset)
+    assert not U._owns_storage(g.t())                       # non-contiguous
+    v = g.view(64, 1024)
+    assert U._owns_storage(v) and not U._inplace_ok(v)      # a view of a tensor somebody holds (here: `g`)
+    v2 = torch.randn(128, 512, device="cuda").bfloat16().view(64, 1024)
+    assert U._inplace_ok(v2)                                # a view of a temporary nobody else can reach (F.linear's wgrad)
+    flat = torch.randn(128 * 512 + 8, device="cuda").bfloat16()
+    assert not U._owns_storage(flat[8:].view(128, 512))
+    with torch.autograd.detect_anomaly(check_nan=False):
+        assert not U._inplace_ok(g)
+    assert U._inplace_ok(g)
+
+
 # ------------------------------------------------------------------------------------------ N-tensor launches (VERDICT r01 item 5)
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
 def test_multi_tensor_launch_matches_separate_calls(pkg, dtype):
@@ -895,7 +1010,7 @@ def test_sibling_projections_share_one_launch(pkg, autocast):
                 o1 = mods[1](xe)
             log.append((ev, o0, o1))
         finally:
-            pkg.group_siblings(True)
+            pkg.group_siblings(False)   # the default
         return log
 
     a, b = run(True), run(False)

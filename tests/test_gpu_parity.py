@@ -309,7 +309,9 @@ def test_error_behaviour_matches_reference(ops):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,bits,style", [((4096, 11008), 4, "weight"), ((4096, 11008), 8, "act"),
                                               ((2048, 4096), 8, "act"), ((2048, 11008), 8, "act"),
-                                              ((2048, 4096), 4, "act"), ((5120, 13824), 4, "weight")])
+                                              ((2048, 4096), 4, "act"), ((5120, 13824), 4, "weight"),
+                                              ((4096, 11008), 8, "weight"),     # config 4 (W8): the +-128 bf16 bin on weight-style rows
+                                              ((2048, 5120), 4, "act")])        # config 5 (13B): KV4 without autocast
 def test_full_size_properties(ops, shape, bits, style):
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.randn(shape, generator=g, device="cuda", dtype=torch.float32)

@@ -5,11 +5,28 @@ operand loads.
   * the product: within the stated fp32-accumulation tolerance of the exact product of those operands, and of
     F.linear(fq(x), fq(W)) as the unfused path computes it
 """
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import oracle as O
+
 pytestmark = pytest.mark.gpu
+
+
+def bits(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def oracle_operand(t, nbits, autocast, rows=None):
+    """the CPU oracle's fake-quantized operand (models/utils_quant.py:71-72; under autocast the fp32 chain rounded once to bf16,
+    which is what F.linear's autocast cast makes of the reference's fp32 result), optionally on a row sample"""
+    t = t if rows is None else t[rows]
+    r, c = t.shape
+    if autocast:
+        return O.sym_fwd_autocast(bits(t), r, c, nbits, "bf16", wide=False)[0].reshape(r, c)
+    return O.sym_fwd(bits(t), r, c, nbits, "bf16", want_idx=False)[0].reshape(r, c)
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +73,9 @@ def test_staged_tiles_are_bit_identical_to_the_quantizer(ops, shape, autocast):
         wq = ops.sym_forward_autocast(w, 4, False, wide=False)[0]
     else:
         xq, wq = ops.sym_quantize(x, 8), ops.sym_quantize(w, 4)
+    # the tiles as the MFMAs saw them against the ORACLE itself (not only against another HIP kernel)
+    assert (bits(sx) == oracle_operand(x, 8, autocast)).all(), "staged x tiles != oracle"
+    assert (bits(sw) == oracle_operand(w, 4, autocast)).all(), "staged W tiles != oracle"
     assert torch.equal(sx.view(torch.int16), xq.view(torch.int16)), "staged x tiles != fq_sym_fwd(x)"
     assert torch.equal(sw.view(torch.int16), wq.view(torch.int16)), "staged W tiles != fq_sym_fwd(W)"
     # the product of exactly those operands.  Tolerance: the result is the fp32-accumulated sum rounded once to bf16;
@@ -81,6 +101,13 @@ def test_llama7b_shape_full_size(ops):
     out, sx, sw = ops.qlinear_forward(x, w, 4, 8, autocast=False, dump=True)
     xq, wq = ops.sym_quantize(x, 8), ops.sym_quantize(w, 4)
     assert torch.equal(sx.view(torch.int16), xq.view(torch.int16)) and torch.equal(sw.view(torch.int16), wq.view(torch.int16))
+    # sampled rows of both staged operands against the oracle (incl. the first / last row of every 256- / 128-row tile edge)
+    rx = torch.unique(torch.cat([torch.arange(0, 2048, 61), torch.tensor([0, 255, 256, 2047])])).cuda()
+    rw = torch.unique(torch.cat([torch.arange(0, 4096, 97), torch.tensor([0, 127, 128, 4095])])).cuda()
+    assert (bits(sx[rx]) == oracle_operand(x, 8, False, rx)).all(), "staged x rows != oracle"
+    assert (bits(sw[rw]) == oracle_operand(w, 4, False, rw)).all(), "staged W rows != oracle"
+    out_ac, sx_ac, sw_ac = ops.qlinear_forward(x, w, 4, 8, autocast=True, dump=True)
+    assert (bits(sx_ac[rx]) == oracle_operand(x, 8, True, rx)).all() and (bits(sw_ac[rw]) == oracle_operand(w, 4, True, rw)).all(), "autocast staging != oracle"
     unf = F.linear(xq, wq).float()
     err = (out.float() - unf).abs()
     scale = unf.abs().mean()

@@ -228,14 +228,19 @@ class Workload:
         b = self.sets[0]["ba"]
         return float(((b[:, 0] >= 2.0) | (b[:, 1] <= -2.0)).float().mean().item())
 
-    def time_kernel(self, fn, iters, sets=None):
-        return time_launches(self.torch, fn, iters, sets if sets is not None else self.sets)
+    def time_kernel(self, fn, iters, sets=None, name=None, fq=1):
+        return time_launches(self.torch, fn, iters, sets if sets is not None else self.sets, name, fq)
 
 
-def time_launches(torch, fn, iters, sets):
+PROFILE_MANIFEST = []   # (entry name, fq:: launches it made), in launch order: lets tools/summarize_profile.py split a rocprofv3
+#                         trace / PMC pass of this process into one segment per entry by counting fq:: dispatches
+
+
+def time_launches(torch, fn, iters, sets, name=None, fq_launches_per_call=1):
     """Launch duration of one kernel kind with HIP events on the launch stream (torch's current stream IS the stream the
     C ABI is handed), rotating buffers.
     -> (mean ms over a back-to-back batch, [p10, p50, p90] ms of individually bracketed launches)"""
+    PROFILE_MANIFEST.append((name or getattr(fn, "__name__", "?"), (3 + 2 * iters) * fq_launches_per_call))
     ns = len(sets)
     for i in range(3):
         fn(sets[i % ns])
@@ -422,7 +427,7 @@ def time_specs(torch, specs, iters, traffic=None, traffic_source=None):
     """roofline entries of a list of launch specs (ModelShapes._spec / export_specs / lowbit_asym_specs)"""
     out = []
     for sp in specs:
-        t = time_launches(torch, sp["fn"], iters, sp["sets"])
+        t = time_launches(torch, sp["fn"], iters, sp["sets"], sp["name"], sp.get("fq", 1))
         e = roofline_entry(sp["name"], sp["algo"], t, (traffic or {}).get(sp["name"]), moved_bytes=sp["moved"], traffic_source=traffic_source)
         if sp.get("site"):
             e["reference_call_site"] = sp["site"]
@@ -825,7 +830,10 @@ def main(argv=None):
     wl.prime_bounds()
     if args.model_shapes:
         return run_model_shapes(args, wl, rank, dist)
+    PROFILE_MANIFEST.append(("prologue: prime_bounds", 2 * wl.nsets))
     seconds = timed_region(wl.step, args.steps, args.warmup, torch.cuda.synchronize, dist)
+    PROFILE_MANIFEST.append(("timed region: step (weight gradient in place)", 2 * (args.steps + args.warmup)))
+    PROFILE_MANIFEST.append(("timed region: step out of place", 2 * (args.steps + args.warmup)))
     # the like-for-like step beside it (both gradients written to fresh tensors), same K / W / barrier / max-over-ranks protocol
     seconds_oop = timed_region(wl.step_out_of_place, args.steps, args.warmup, torch.cuda.synchronize, dist)
     elems_step = 2 * wl.n
@@ -884,28 +892,29 @@ def main(argv=None):
         }
 
         def pair_traffic(k):
-            if "in place" in k:
-                return traffic.get("ste_bwd_pair_w4a8_inplace")
             if k in traffic:
                 return traffic[k]
+            if "in place" in k:
+                return traffic.get("ste_bwd_pair_w4a8_inplace")
             parts = {"sym_fwd_pair_w4a8": ("sym_fwd_w4", "sym_fwd_a8")}.get(k)
             return sum(traffic[p] for p in parts) if parts and all(p in traffic for p in parts) else None
 
-        out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it), pair_traffic(k), moved_bytes=mv, traffic_source=tsrc)
+        out["kernels_step"] = [roofline_entry(k, b, wl.time_kernel(fn, it, name=k), pair_traffic(k), moved_bytes=mv, traffic_source=tsrc)
                                for k, (fn, b, mv) in pk.items()]
-        out["kernels"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), moved_bytes=mv, traffic_source=tsrc)
+        out["kernels"] = [roofline_entry(k, b, wl.time_kernel(fn, it, name=k), traffic.get(k), moved_bytes=mv, traffic_source=tsrc)
                           for k, (fn, b, mv) in ks.items()]
         # the reference's data flow on the same kernels' siblings: forward without mask/bounds, backward re-reading x
         alt = {
             "sym_fwd_w4_plain": (lambda s: wl.fwd_plain(s, "w"), nb * FWD_BYTES_PER_ELEM),
             "ste_bwd_a8_xread": (lambda s: wl.bwd_xread(s, "a"), nb * BWD_BYTES_PER_ELEM),
         }
-        out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in alt.items()]
+        out["kernels_reference_dataflow"] = [roofline_entry(k, b, wl.time_kernel(fn, it, name=k), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in alt.items()]
         # the backward as a copy (gx != g for the weight too: what round 1 measured) and the weight's in-place launch alone
         out["kernels_step_out_of_place"] = [roofline_entry("ste_bwd_pair_w4a8 (both gradients to fresh tensors)", 2 * nb * BWD_BYTES_PER_ELEM,
-                                                           wl.time_kernel(lambda s: wl.bwd_pair(s, inplace_w=False), it), traffic.get("ste_bwd_pair_w4a8"),
+                                                           wl.time_kernel(lambda s: wl.bwd_pair(s, inplace_w=False), it, name="ste_bwd_pair_w4a8 (both gradients to fresh tensors)"),
+                                                           traffic.get("ste_bwd_pair_w4a8 (both gradients to fresh tensors)", traffic.get("ste_bwd_pair_w4a8")),
                                                            moved_bytes=bwd_w + bwd_a, traffic_source=tsrc)]
-        tw = (0.0, [0.0, 0.0, 0.0]) if args.core_extras else wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it)
+        tw = wl.time_kernel(lambda s: wl.bwd(s, "w", inplace=True), it, name="ste_bwd_w4_in_place")
         out["ste_bwd_w4_in_place"] = {"us_per_launch": round(tw[0] * 1e3, 2), "us_p10_p50_p90": [round(v * 1e3, 2) for v in tw[1]],
                                       "what": "fq_ste_bwd_mask with gx == g on the W4 tensor: every row's bounds prove nothing clips; one block per 256 "
                                               "rows reads their bounds (8 B per row) and exits"}
@@ -914,7 +923,7 @@ def main(argv=None):
             "sym_fwd_a8_autocast_bf16_out": (lambda s: wl.fwd_autocast(s, "a", False), nb * FWD_BYTES_PER_ELEM),
             "sym_fwd_a8_autocast_fp32_out": (lambda s: wl.fwd_autocast(s, "a", True), nb * 6),  # read 2 + write 4 B/elem
         }
-        out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in ac.items()]
+        out["kernels_autocast_arithmetic"] = [roofline_entry(k, b, wl.time_kernel(fn, it, name=k), traffic.get(k), traffic_source=tsrc) for k, (fn, b) in ac.items()]
         # `roofline`: the forward launch of the step (row_reg_kernel over the W4 weight and the A8 input: reduce -> scale ->
         # round -> dequant): achieved = ALGORITHMIC bytes (4 B/elem x 90.2 M elements) / its launch time.
         fwp = out["kernels_step"][0]
@@ -943,7 +952,9 @@ def main(argv=None):
             out["autograd_path"] = autograd_path(wl)
         # a live yardstick for "how fast can this device move the same bytes": ATen's device-to-device copy of the W tensor
         # (read 90.2 MB + write 90.2 MB = one single-tensor forward's algorithmic bytes), timed like the kernels above
-        cmean, cpct = wl.time_kernel(lambda s: s["yw"].copy_(s["w"]), it)
+        cmean, cpct = wl.time_kernel(lambda s: s["yw"].copy_(s["w"]), it, name="copy_reference (ATen)", fq=0)
+        if args.core_extras:
+            out["profile_manifest"] = [list(m) for m in PROFILE_MANIFEST]   # every fq:: launch of this process, in order
         out["copy_reference"] = {"what": "torch Tensor.copy_ device-to-device over the same 180.4 MB as sym_fwd_w4 (compare kernels[0])",
                                  "us_per_launch": round(cmean * 1e3, 2), "gbs": round(nb * FWD_BYTES_PER_ELEM / (cmean * 1e-3) / 1e9, 1),
                                  "us_p10_p50_p90": [round(v * 1e3, 2) for v in cpct]}
@@ -1055,7 +1066,8 @@ def run_model_shapes(args, wl, rank, dist):
     entries = time_specs(torch, specs, iters, mtraffic, msrc)
     calls = 3 + 2 * iters   # time_launches: 3 warm-up + iters back-to-back + iters individually bracketed
     out = {"mode": "model-shapes", "fq_launches_per_entry": calls, "prologue_fq_launches": 2 * wl.nsets,
-           "entries": entries, "order": [sp["name"] for sp in specs]}
+           "entries": entries, "order": [sp["name"] for sp in specs],
+           "profile_manifest": [["prologue: prime_bounds", 2 * wl.nsets]] + [list(m) for m in PROFILE_MANIFEST]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,6 +148,28 @@ __global__ __launch_bounds__(256) void write_kernel(uint4* __restrict__ out, int
     }
 }
 
+// 8 bytes per lane (the fp32-result kernels read 16-bit rows / write 16-bit gradients in 8-byte half-vectors): PMC calibration
+__global__ __launch_bounds__(256) void read8_kernel(const uint2* __restrict__ in, uint32_t* __restrict__ out, int64_t n8) {
+    const int64_t v0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int64_t v = v0 + (int64_t)i * 256;
+        v = v < n8 ? v : n8 - 1;
+        const uint2 r = in[v];
+        acc |= r.x ^ r.y;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void write8_kernel(uint2* __restrict__ out, int64_t n8) {
+    const int64_t v0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t v = v0 + (int64_t)i * 256;
+        if (v < n8) out[v] = make_uint2((uint32_t)v, 7);
+    }
+}
+
 // ---------------------------------------------------------------- harness
 struct Bufs {
     std::vector<void*> x, y, g, gx;
@@ -272,9 +294,23 @@ int main(int argc, char** argv) {
                                   (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec / R);                                        \
            }, IT));
     SHRINK(2) SHRINK(4)
-    if (argc > 3 && std::string(argv[3]) == "ceilings") return 0;
     uint32_t* sink;
     CK(hipMalloc(&sink, 64));
+    report("read-only 8 B/lane", 1.0 * bytes, time_it([&](int i) {
+               hipLaunchKernelGGL(read8_kernel, dim3((unsigned)((2 * nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint2*)b.x[i % NS], sink, 2 * nvec);
+           }, IT));
+    report("write-only 8 B/lane", 1.0 * bytes, time_it([&](int i) {
+               hipLaunchKernelGGL(write8_kernel, dim3((unsigned)((2 * nvec + 1023) / 1024)), dim3(256), 0, 0, (uint2*)b.y[i % NS], 2 * nvec);
+           }, IT));
+    if (argc > 3 && std::string(argv[3]) == "ceilings") {
+        report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
+                   hipLaunchKernelGGL((read_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);
+               }, IT));
+        report("write-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
+                   hipLaunchKernelGGL((write_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (uint4*)b.y[i % NS], nvec);
+               }, IT));
+        return 0;
+    }
     report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
                hipLaunchKernelGGL((read_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);
            }, IT));

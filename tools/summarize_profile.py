@@ -3,15 +3,23 @@
 
     python tools/summarize_profile.py <tag>
 
-Writes
-  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --steps 50 --warmup 5`
-  profiles/<tag>_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes), with the
-                                    calibration on kernels of known byte count and the gfx950 correction
-  profiles/traffic.json             HBM bytes per launch for bench.py's `roofline.traffic`
+bench.py prints, in both profiled modes, a `profile_manifest`: every fq:: launch the process made, in order, as
+(entry name, number of launches).  rocprofv3's per-dispatch rows (kernel trace / counter collection) are sorted by
+dispatch id, filtered to fq:: kernels and cut into one segment per entry by those counts -- no guessing from kernel names
+or grid sizes, and two roles that share a kernel and a grid are still told apart.  A count mismatch aborts.
 
-Correction (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
-streaming read -> doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Both are in KiB.
-The calibration rows (plain copy / read-only / write-only of a 90,177,536-byte buffer in tools/kbench) confirm both.
+Writes
+  profiles/<tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats summary of `bench.py --core-extras` (per kernel)
+  profiles/<tag>_step_kernels.json           per ENTRY of that run: rocprofv3 average duration, FETCH_SIZE / WRITE_SIZE bytes
+  profiles/<tag>_model_shapes_profile.json   the same per entry of `bench.py --model-shapes` (+ bench.py's own HIP-event time)
+  profiles/<tag>_model_shapes_kernel_stats.csv
+  profiles/<tag>_pmc_calibration.json        the counters on kernels of known byte count (tools/kbench ... ceilings)
+  profiles/traffic.json, profiles/traffic_model_shapes.json   HBM bytes per launch keyed by entry name, for bench.py's `traffic`
+
+Correction (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming
+read (16 B per lane) -> doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Both are in KiB.  Other access
+widths are uncalibrated by the guide: the 8-byte-per-lane kernels of tools/kbench calibrate them here, and entries whose
+kernel uses such accesses carry the note.
 """
 import collections
 import csv
@@ -20,30 +28,83 @@ import json
 import os
 import statistics
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOWN = 4096 * 11008 * 2
 
 
-def counters(path, by_grid=False):
-    """counter values per kernel; by_grid: key = (kernel name, grid size) so that paired (two-tensor) launches of the
-    same kernel are kept apart from single-tensor ones"""
-    d = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(path, "runc", "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            d[(r["Kernel_Name"], int(r["Grid_Size"])) if by_grid else r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return d
-
-
-def ac_flag(name):
-    """last template argument of row_reg_kernel (AC: 0 = plain arithmetic, 1 = autocast)"""
-    import re
-    m = re.search(r"row_reg_kernel<[^>]*,\s*(\d)>", name)
-    return int(m.group(1)) if m else None
-
-
 def short(name):
     return name.replace("void ", "").split("(")[0]
+
+
+def rows_of(path, pattern):
+    out = []
+    for f in sorted(glob.glob(os.path.join(path, "*", pattern))):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+def fq_dispatches(path, counters):
+    """fq:: dispatches in launch order: [(kernel, value)] -- value = counter value (counters) or duration in ns (trace)"""
+    if counters:
+        rows = rows_of(path, "*_counter_collection.csv")
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        return [(short(r["Kernel_Name"]), float(r["Counter_Value"])) for r in rows if "fq::" in r["Kernel_Name"]]
+    rows = rows_of(path, "*_kernel_trace.csv")
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [(short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if "fq::" in r["Kernel_Name"]]
+
+
+def manifest_of(log):
+    """the profile_manifest bench.py printed (stdout of the profiled run)"""
+    for line in reversed(open(log).read().splitlines()):
+        if not line.startswith("{"):
+            continue
+        d = json.loads(line)
+        if d.get("bench_extras") == "profile_manifest":
+            return d["data"], None
+        if "profile_manifest" in d:
+            return d["profile_manifest"], d
+    raise SystemExit(f"no profile_manifest in {log}")
+
+
+def segments(dispatches, manifest, what):
+    total = sum(n for _, n in manifest)
+    if total != len(dispatches):
+        raise SystemExit(f"{what}: the manifest announces {total} fq:: launches, the profile holds {len(dispatches)}")
+    out, pos = collections.OrderedDict(), 0
+    for name, n in manifest:
+        if n:
+            out[name] = dispatches[pos:pos + n]
+        pos += n
+    return out
+
+
+def steady(vals, n_warm=3):
+    """values of an entry's launches without its warm-up launches"""
+    return vals[n_warm:] if len(vals) > n_warm + 2 else vals
+
+
+def per_entry(src, prefix, log_name):
+    manifest, doc = manifest_of(os.path.join(src, log_name))
+    tr = segments(fq_dispatches(os.path.join(src, prefix + "trace"), False), manifest, prefix + "trace")
+    fe = segments(fq_dispatches(os.path.join(src, prefix + "fetch"), True), manifest, prefix + "fetch")
+    wr = segments(fq_dispatches(os.path.join(src, prefix + "write"), True), manifest, prefix + "write")
+    res = collections.OrderedDict()
+    for name in tr:
+        if name.startswith(("prologue", "timed region")):
+            continue
+        kernels = sorted(set(k for k, _ in tr[name]))
+        d = [v for _, v in steady(tr[name])]
+        f = [v for _, v in steady(fe[name])]
+        w = [v for _, v in steady(wr[name])]
+        rd, wb = statistics.median(f) * 2048.0, statistics.median(w) * 1024.0
+        res[name] = {"kernel": kernels[0] if len(kernels) == 1 else kernels, "launches_profiled": len(d),
+                     "rocprof_avg_us": round(statistics.mean(d) / 1e3, 2), "rocprof_min_us": round(min(d) / 1e3, 2),
+                     "FETCH_SIZE_KiB_raw": statistics.median(f), "WRITE_SIZE_KiB_raw": statistics.median(w),
+                     "read_bytes": rd, "write_bytes": wb, "hbm_bytes": rd + wb}
+    return res, manifest, doc
 
 
 def main():
@@ -51,144 +112,77 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
+    cmd_step = "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras --no-sidecar"
+    cmd_ms = "python3 bench.py --model-shapes --steps 30"
 
-    # 1. kernel-trace stats
-    stats = glob.glob(os.path.join(src, "trace", "runc", "*_kernel_stats.csv"))[0]
-    rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras  (MI355X, gfx950)"])
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows:
-            w.writerow([short(r["Name"])[:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-
-    # per-dispatch durations of the STE kernel split by safe/unsafe cannot be told from the stats file; use the trace
-    trace = glob.glob(os.path.join(src, "trace", "runc", "*_kernel_trace.csv"))[0]
-    dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace)):
-        if "fq::" in r["Kernel_Name"]:
-            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-
-    # 1b. the same trace split by grid size: paired (two-tensor) launches of a kernel are twice as long as single ones
-    by_grid = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace)):
-        if "fq::" in r["Kernel_Name"]:
-            by_grid[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    with open(os.path.join(out, f"{tag}_kernel_stats_by_grid.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["# same rocprofv3 kernel trace, fq:: kernels split by grid size (the larger grid of a kernel = the paired weight+input launch)"])
-        w.writerow(["Name", "Grid_Size_X", "Calls", "AverageNs", "MinNs", "MaxNs"])
-        for (name, grid), v in sorted(by_grid.items()):
-            lo_, hi_ = min(v), max(v)
-            cut = (lo_ + hi_) / 2
-            a, b = [x for x in v if x < cut], [x for x in v if x >= cut]
-            if hi_ > 1.5 * lo_ and min(len(a), len(b)) >= 10:   # two populations behind one kernel name and grid (e.g. the paired STE
-                # backward with the weight's gradient in place vs copied): report them apart
-                w.writerow([name + "  [faster population]", grid, len(a), round(statistics.mean(a), 1), min(a), max(a)])
-                w.writerow([name + "  [slower population]", grid, len(b), round(statistics.mean(b), 1), min(b), max(b)])
-            else:
-                w.writerow([name, grid, len(v), round(statistics.mean(v), 1), lo_, hi_])
-
-    # 2. PMC traffic
-    res = {"unit": "bytes per launch", "correction": "FETCH_SIZE KiB x 2 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1",
-           "calibration": {}, "kernels": {}}
-    kbf, kbw = counters(os.path.join(src, "kb_fetch")), counters(os.path.join(src, "kb_write"))
-    for name in kbf:
-        if any(k in name for k in ("copy_kernel<4, false>", "copy_kernel<4, true>", "read_kernel<4>", "write_kernel<4>")):
-            res["calibration"][short(name)] = {
-                "known_read_bytes": 0 if "write_kernel" in name else KNOWN, "known_write_bytes": 0 if "read_kernel" in name else KNOWN,
-                "FETCH_SIZE_KiB_raw": statistics.median(kbf[name]), "WRITE_SIZE_KiB_raw": statistics.median(kbw.get(name, [0])),
-                "read_bytes_corrected": statistics.median(kbf[name]) * 2 * 1024, "write_bytes": statistics.median(kbw.get(name, [0])) * 1024}
-    bf, bw = counters(os.path.join(src, "fetch"), True), counters(os.path.join(src, "write"), True)
-    single_grid = {}
-    for (name, grid) in bf:   # the smallest grid of a kernel = its single-tensor launches
-        single_grid[name] = min(grid, single_grid.get(name, grid))
-    traffic = {}
-
-    def split(vals):
-        """bimodal counter values -> (low cluster, high cluster); one cluster if the spread is < 1 %"""
-        lo, hi = min(vals), max(vals)
-        if hi - lo < 0.01 * hi:
-            return vals, []
-        cut = (lo + hi) / 2
-        return [v for v in vals if v < cut], [v for v in vals if v >= cut]
-
-    for (name, grid) in sorted(bf):
-        if "fq::" not in name:
+    # 0. rocprofv3 --stats summaries, per kernel name (as rocprofv3 prints them)
+    for sub, dst, cmd in (("trace", f"{tag}_kernel_stats.csv", cmd_step), ("ms_trace", f"{tag}_model_shapes_kernel_stats.csv", cmd_ms)):
+        files = sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")))
+        if not files:
             continue
-        fv, wv = bf[(name, grid)], bw.get((name, grid), [])
-        entry = {"launches": len(fv), "grid_size": grid}
-        if grid != single_grid[name]:   # a paired launch (weight + input of a QuantizeLinear)
-            if "ste_mask_kernel" in name:
-                # two populations share this kernel and grid: the step's backward with the weight's gradient IN PLACE (the W4
-                # half moves nothing) and the copying variant (both gradients to fresh tensors)
-                f_lo, f_hi = split(fv)
-                w_lo, w_hi = split(wv) if wv else ([], [])
-                med = statistics.median
-                lo_total = med(f_lo) * 2048 + (med(w_lo) * 1024 if w_lo else 0)
-                entry.update({"paired_launch": True})
-                if f_hi:
-                    hi_total = med(f_hi) * 2048 + (med(w_hi if w_hi else w_lo) * 1024 if (w_hi or w_lo) else 0)
-                    entry["weight_gradient_in_place"] = {"read_bytes": med(f_lo) * 2048, "write_bytes": med(w_lo) * 1024 if w_lo else 0, "total": lo_total, "launches": len(f_lo)}
-                    entry["both_to_fresh_tensors"] = {"read_bytes": med(f_hi) * 2048, "write_bytes": med(w_hi if w_hi else w_lo) * 1024, "total": hi_total, "launches": len(f_hi)}
-                    traffic["ste_bwd_pair_w4a8_inplace"] = lo_total
-                    traffic["ste_bwd_pair_w4a8"] = hi_total
-                else:
-                    entry.update({"read_bytes": med(f_lo) * 2048, "write_bytes": med(w_lo) * 1024 if w_lo else 0, "total": lo_total})
-                    traffic["ste_bwd_pair_w4a8"] = lo_total
-                res["kernels"][short(name) + f" [grid {grid}]"] = entry
-                continue
-            rd, wr = statistics.median(fv) * 2048, (statistics.median(wv) * 1024 if wv else 0)
-            entry.update({"paired_launch": True, "read_bytes": rd, "write_bytes": wr, "total": rd + wr})
-            if "row_reg_kernel" in name and ac_flag(name) == 0:
-                traffic["sym_fwd_pair_w4a8"] = rd + wr
-            res["kernels"][short(name) + f" [grid {grid}]"] = entry
-            continue
-        f_lo, f_hi = split(fv)
-        w_lo, w_hi = split(wv) if wv else ([], [])
-        med = statistics.median
-        if "ste_rows" in name or "ste_mask" in name:
-            # bimodal on the READ side: rows provably unclipped (g only) vs rows that need x / the bit mask
-            wr = med(wv) * 1024 if wv else 0
-            entry["rows_safe"] = {"read_bytes": med(f_lo) * 2048, "write_bytes": wr, "total": med(f_lo) * 2048 + wr, "launches": len(f_lo)}
-            traffic["ste_bwd_w4"] = entry["rows_safe"]["total"]
-            if f_hi:
-                entry["rows_clippable"] = {"read_bytes": med(f_hi) * 2048, "write_bytes": wr, "total": med(f_hi) * 2048 + wr, "launches": len(f_hi)}
-                traffic["ste_bwd_a8"] = entry["rows_clippable"]["total"]
-        elif "row_reg_kernel" in name and ac_flag(name) != 0:
-            rd = med(fv) * 2048
-            wr = med(wv) * 1024 if wv else None
-            entry.update({"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0), "note": "autocast arithmetic"})
-        elif "row_reg_kernel" in name:
-            # bimodal on the WRITE side in training mode: the A8 leg also writes the 1-bit STE mask
-            rd = med(fv) * 2048
-            entry["no_mask_rows"] = {"read_bytes": rd, "write_bytes": med(w_lo) * 1024 if w_lo else None, "launches": len(w_lo)}
-            traffic["sym_fwd_w4"] = rd + (med(w_lo) * 1024 if w_lo else 0)
-            traffic["sym_fwd_a8"] = traffic["sym_fwd_w4"]
-            if w_hi:
-                entry["mask_rows"] = {"read_bytes": rd, "write_bytes": med(w_hi) * 1024, "launches": len(w_hi)}
-                traffic["sym_fwd_a8"] = rd + med(w_hi) * 1024
-        else:
-            rd = med(fv) * 2048
-            wr = med(wv) * 1024 if wv else None
-            entry.update({"read_bytes": rd, "write_bytes": wr, "total": rd + (wr or 0)})
-            if "ste_vec_kernel" in name:
-                traffic["ste_bwd_a8_xread"] = entry["total"]
-        d = dur.get(short(name))
-        if d:
-            entry["avg_duration_ns_unprofiled_trace"] = statistics.mean(d)
-        res["kernels"][short(name) + f" [grid {grid}]"] = entry
-    if "sym_fwd_w4" in traffic:
-        traffic["sym_fwd_w4_plain"] = traffic["sym_fwd_w4"]
-    json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-    import time
-    traffic["_source"] = (f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, FETCH_SIZE x2 per the gfx950 "
-                          f"rule) of `bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras`, collected {time.strftime('%Y-%m-%d')} on one MI355X; "
-                          "NOT measured in the run that prints this line")
+        rows = list(csv.DictReader(open(files[0])))
+        with open(os.path.join(out, dst), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow([f"# rocprofv3 --kernel-trace --stats -- {cmd}  (MI355X, gfx950)"])
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"])[:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+    # 1. calibration: kernels of known byte count
+    cal = {"unit": "bytes per launch", "known_bytes_per_stream": KNOWN,
+           "rule": "FETCH_SIZE KiB x 2 x 1024 (gfx950 wide-read undercount), WRITE_SIZE KiB x 1024", "kernels": {}}
+    kf = collections.defaultdict(list)
+    kw = collections.defaultdict(list)
+    for r in rows_of(os.path.join(src, "kb_fetch"), "*_counter_collection.csv"):
+        kf[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for r in rows_of(os.path.join(src, "kb_write"), "*_counter_collection.csv"):
+        kw[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for name in sorted(kf):
+        if any(k in name for k in ("copy_kernel<1, true>", "copy_kernel<4, false>", "copy_kernel<4, true>", "read_kernel<4>", "write_kernel<4>", "read8_kernel",
+                                   "write8_kernel", "shrink_kernel")):
+            reads = 0 if "write" in name else KNOWN
+            writes = 0 if "read" in name else (KNOWN // 2 if "shrink_kernel<2" in name else KNOWN // 4 if "shrink_kernel<4" in name else KNOWN)
+            rd, wb = statistics.median(kf[name]) * 2048.0, statistics.median(kw.get(name, [0])) * 1024.0
+            cal["kernels"][name] = {"known_read_bytes": reads, "known_write_bytes": writes, "read_bytes_counted_x2": rd, "write_bytes_counted": wb,
+                                    "read_ratio": round(rd / reads, 4) if reads else None, "write_ratio": round(wb / writes, 4) if writes else None}
+    json.dump(cal, open(os.path.join(out, f"{tag}_pmc_calibration.json"), "w"), indent=1)
+
+    stamp = time.strftime("%Y-%m-%d")
+    # 2. the step's kernels (bench.py --core-extras)
+    step, _, _ = per_entry(src, "", "trace.log")
+    json.dump({"command": cmd_step, "collected": stamp, "note": "one entry per role of the timed step; rocprof_avg_us = rocprofv3 --kernel-trace duration, "
+               "hbm_bytes = FETCH_SIZE x 2 KiB + WRITE_SIZE KiB of the separate --pmc passes (medians over the entry's launches, warm-up launches dropped)",
+               "entries": step}, open(os.path.join(out, f"{tag}_step_kernels.json"), "w"), indent=1)
+    traffic = {k: v["hbm_bytes"] for k, v in step.items()}
+    traffic["_source"] = (f"profiles/{tag}_step_kernels.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, FETCH_SIZE x2 per the gfx950 rule) of "
+                          f"`{cmd_step}`, collected {stamp} on one MI355X; NOT measured in the run that prints this line")
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    print(json.dumps(traffic, indent=1))
-    for k, v in dur.items():
-        print(f"{k[:90]:92s} n={len(v):4d} avg={statistics.mean(v)/1e3:8.2f} us  min={min(v)/1e3:8.2f}")
+
+    # 3. one layer's launch kinds, export, W1/W2 one-launch, Asym (bench.py --model-shapes)
+    ms, _, doc = per_entry(src, "ms_", "ms_trace.log")
+    bench_us = {e["kernel"]: e for e in doc["entries"]}
+    narrow = {"quantize_kv pair fwd under autocast: fp32 results": "loads 8 B per lane", "quantize_kv pair bwd under autocast: fp32 grads in, bf16 out": "stores 8 B per lane"}
+    for name, v in ms.items():
+        b = bench_us.get(name)
+        if b:
+            v["bench_hip_event_us_under_profiler"] = b["us_per_launch"]
+            v["bytes_moved_by_design"] = b["bytes_moved_per_launch"]
+            v["algorithmic_bytes"] = b["algorithmic_bytes_per_launch"]
+            v["hbm_over_moved"] = round(v["hbm_bytes"] / b["bytes_moved_per_launch"], 4)
+            v["achieved_GBs_rocprof"] = round(b["bytes_moved_per_launch"] / (v["rocprof_avg_us"] * 1e-6) / 1e9, 1)
+        if name in narrow:
+            v["note"] = f"{narrow[name]}: see the 8-byte calibration kernels in {tag}_pmc_calibration.json"
+    json.dump({"command": cmd_ms, "collected": stamp, "entries": ms}, open(os.path.join(out, f"{tag}_model_shapes_profile.json"), "w"), indent=1)
+    tms = {k: v["hbm_bytes"] for k, v in ms.items()}
+    tms["_source"] = (f"profiles/{tag}_model_shapes_profile.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, FETCH_SIZE x2) of `{cmd_ms}`, "
+                      f"collected {stamp} on one MI355X; NOT measured in the run that prints this line")
+    json.dump(tms, open(os.path.join(out, "traffic_model_shapes.json"), "w"), indent=1)
+
+    for title, d in (("step kernels", step), ("model shapes", ms)):
+        print(f"== {title}")
+        for k, v in d.items():
+            extra = f"  hbm/moved {v['hbm_over_moved']:.3f}  bench-under-profiler {v['bench_hip_event_us_under_profiler']:.2f} us" if "hbm_over_moved" in v else ""
+            print(f"{k[:84]:86s} {v['rocprof_avg_us']:8.2f} us  hbm {v['hbm_bytes'] / 1e6:8.2f} MB{extra}")
 
 
 if __name__ == "__main__":

@@ -240,9 +240,10 @@ def time_launches(torch, fn, iters, sets, name=None, fq_launches_per_call=1):
     """Launch duration of one kernel kind with HIP events on the launch stream (torch's current stream IS the stream the
     C ABI is handed), rotating buffers.
     -> (mean ms over a back-to-back batch, [p10, p50, p90] ms of individually bracketed launches)"""
-    PROFILE_MANIFEST.append((name or getattr(fn, "__name__", "?"), (3 + 2 * iters) * fq_launches_per_call))
     ns = len(sets)
-    for i in range(3):
+    warm = max(3, ns)   # every buffer set once: the first launches that touch freshly allocated memory run 30-50 % slow on small tensors
+    PROFILE_MANIFEST.append((name or getattr(fn, "__name__", "?"), (warm + 2 * iters) * fq_launches_per_call))
+    for i in range(warm):
         fn(sets[i % ns])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -1064,8 +1065,7 @@ def run_model_shapes(args, wl, rank, dist):
     specs = ModelShapes(wl).specs() + export_specs(wl) + lowbit_asym_specs(wl, fused_only=True)
     mtraffic, msrc = load_traffic("traffic_model_shapes.json")
     entries = time_specs(torch, specs, iters, mtraffic, msrc)
-    calls = 3 + 2 * iters   # time_launches: 3 warm-up + iters back-to-back + iters individually bracketed
-    out = {"mode": "model-shapes", "fq_launches_per_entry": calls, "prologue_fq_launches": 2 * wl.nsets,
+    out = {"mode": "model-shapes", "prologue_fq_launches": 2 * wl.nsets,
            "entries": entries, "order": [sp["name"] for sp in specs],
            "profile_manifest": [["prologue: prime_bounds", 2 * wl.nsets]] + [list(m) for m in PROFILE_MANIFEST]}
     if dist is not None:

@@ -16,6 +16,7 @@
 #include "fq_device.h"
 
 
+
 namespace fq {
 
 constexpr int MAX_MORE = 3;  // up to 4 tensors per launch (q/k/v weights + their shared input)
@@ -104,6 +105,8 @@ template <int DT> __device__ __forceinline__ void ste_mask_record(uint8_t* mrow,
         uint32_t m;
         if (clipk) m = ste_flags16_vec(raw, clipk);          // wave-uniform choice
         else m = sym_clip ? ste_flags_f<8, true>(f, lo, hi) : ste_flags_f<8, false>(f, lo, hi);
+        // (gathering a quad's four bytes into one dword store from its first lane -- 16 storing lanes instead of 64 -- measured
+        // 1 % slower on the [2048,4096] launches: profiles/r03_ab_mask_store_dword.txt)
         if (in_range) mrow[v] = (uint8_t)m;
     } else {
         uint32_t nib = sym_clip ? ste_flags_f<4, true>(f, lo, hi) : ste_flags_f<4, false>(f, lo, hi);

@@ -155,6 +155,15 @@ class SymQuantizer(_FakeQuantFunction):
     def forward(ctx, input, clip_val, num_bits, layerwise):
         return _FakeQuantFunction._fwd("sym", ctx, input, clip_val, num_bits, layerwise)
 
+    @classmethod
+    def apply(cls, input, clip_val, num_bits, layerwise):
+        # the unchanged KV-cache hooks (two consecutive apply calls on k_proj's and v_proj's outputs): one launch, see point 7
+        if _PAIR_KV and cls is SymQuantizer and not layerwise:
+            out = _kv_hook(input, clip_val, num_bits)
+            if out is not None:
+                return out
+        return super().apply(input, clip_val, num_bits, layerwise)
+
 
 class _SymQuantizerOperand(_FakeQuantFunction):
     """SymQuantizer for QuantizeLinear's own operands: identical, except that under autocast it hands F.linear the
@@ -544,6 +553,74 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
     return (SymQuantizer.apply(k, clip_val_k, num_bits, False), SymQuantizer.apply(v, clip_val_v, num_bits, False))
 
 
+# 7. The KV-cache hooks as the reference writes them (models/modeling_llama_quant.py:317-327),
+#        key_states = self.k_proj(hidden_states);  value_states = self.v_proj(hidden_states)
+#        key_states   = SymQuantizer.apply(key_states,   clip_k, kv_bits, False)
+#        value_states = SymQuantizer.apply(value_states, clip_v, kv_bits, False)
+#    are two launches forward and two backward on tensors of one shape.  With the call site UNTOUCHED: every QuantizeLinear
+#    notes its output (a weak reference, per thread); when SymQuantizer.apply receives such an output and the very next noted
+#    output has the same shape / dtype / device (K, then V), both are fake-quantized in ONE launch (the quantize_kv path), K's
+#    result is returned and V's is kept for the apply call that follows -- which must present that very tensor, unmodified, with
+#    the same clip / bits / grad mode / autocast state and no fake-quant backward in between; anything else discards it (the
+#    speculation then cost one tensor's forward, nothing else: a V result nobody asks for simply never receives a gradient).
+#    The decision depends only on the call sequence, so a checkpointed forward and its recompute build the same graph.
+#    Results and gradients are bit-identical to the two calls (tests/test_tiny_llama.py, tests/test_gpu_features.py).
+#    LLMQAT_AMD_PAIR_KV=0 / pair_kv_hooks(False) turn it off.
+_PAIR_KV = os.environ.get("LLMQAT_AMD_PAIR_KV", "1") != "0"
+
+
+def pair_kv_hooks(flag=True):
+    global _PAIR_KV
+    _PAIR_KV = bool(flag)
+
+
+def _note_output(out):
+    """QuantizeLinear.forward: remember (weakly) the last few outputs of this thread, in order"""
+    rec = getattr(_tls, "outs", None)
+    if rec is None:
+        rec = _tls.outs = []
+    if len(rec) >= 4:
+        del rec[0]
+    rec.append((weakref.ref(out), out._version))
+
+
+def _kv_state(clip_val, num_bits):
+    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops.get_semantics(), _bwd_epoch[0])
+
+
+def _kv_hook(x, clip_val, num_bits):
+    """-> the fake-quantized x if it is served from / by a K+V pair launch, else None (the ordinary single call runs)"""
+    if not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 2 <= num_bits < 32 and x.dim() <= 3) or torch.compiler.is_compiling():
+        return None
+    stash = getattr(_tls, "kv_stash", None)
+    if stash is not None:
+        _tls.kv_stash = None
+        ref, ver, vq, state = stash
+        if ref() is x and ver == x._version and state == _kv_state(clip_val, num_bits):
+            return vq   # V: quantized together with K a moment ago
+    rec = getattr(_tls, "outs", None)
+    if not rec:
+        return None
+    for i in range(len(rec) - 1):
+        if rec[i][0]() is x:
+            if rec[i][1] != x._version:
+                return None
+            v, vver = rec[i + 1][0](), rec[i + 1][1]
+            if (v is None or v is x or vver != v._version or v.shape != x.shape or v.dtype != x.dtype or v.device != x.device
+                    or not v.is_contiguous() or not x.is_contiguous() or v.requires_grad != x.requires_grad):
+                return None
+            lo, hi = _clip_pair(clip_val)
+            grad = torch.is_grad_enabled()
+            need = grad and x.requires_grad
+            res = ops.pair_forward(x, v, num_bits, num_bits, lo, hi, need, need, wide=True)
+            if res is None:
+                return None
+            kq, vq = _PairNode.apply(x, v, res, (lo, hi)) if need else (res[0], res[1])
+            _tls.kv_stash = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits))
+            return kq
+    return None
+
+
 class _ReuseQuantizedWeight(torch.autograd.Function):
     """Autograd node over an already computed (value, row bounds, STE mask) triple of a weight:
     forward launches nothing, backward is the ordinary STE backward."""
@@ -805,6 +882,12 @@ class QuantizeLinear(nn.Linear):
         return out
 
     def forward(self, input_):
+        out = self._forward(input_)
+        if _PAIR_KV and out.is_cuda and not torch.compiler.is_compiling():
+            _note_output(out)   # the KV-cache hooks may follow (point 7)
+        return out
+
+    def _forward(self, input_):
         assert len(self.weight.size()) == 2
         if torch.compiler.is_compiling():
             return self._forward_compiled(input_)

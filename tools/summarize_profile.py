@@ -81,9 +81,11 @@ def segments(dispatches, manifest, what):
     return out
 
 
-def steady(vals, n_warm=3):
-    """values of an entry's launches without its warm-up launches"""
-    return vals[n_warm:] if len(vals) > n_warm + 2 else vals
+def steady(vals):
+    """values of an entry's launches without its warm-up launches (bench.time_launches: warm-up, then 2 x iters timed launches;
+    the warm-up is at most a third of the entry)"""
+    n_warm = len(vals) // 3
+    return vals[n_warm:] if len(vals) > 8 else vals
 
 
 def per_entry(src, prefix, log_name):

@@ -76,6 +76,49 @@ def test_low_bit_module_vs_live_aten(pkg, dtype):
                 assert torch.equal(lin.weight.grad, wref.grad)       # identity STE for these branches
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_low_bit_chain_stress_vs_oracle(pkg, dtype):
+    """Round 3 rewrote the 1-/2-bit elementwise chain (packed fp32, steps that are provably the identity for an ordinary scale
+    removed, odd cases behind wave-uniform branches).  Randomized stress of BOTH kernels that share it against the oracle's op-by-op
+    chain (utils_quant.py:203-242), with the scale given (so the summation order plays no part): ordinary, zero, denormal, tiny,
+    huge, infinite and NaN scales (the ordinary-scale fast path is guarded by sc in [2^-60, 2^100]); w with +-0, NaN, +-inf,
+    denormals, values on and around the clamp bounds, quotients that round to zero; vector-aligned and odd widths."""
+    import os
+    rng = np.random.default_rng({"bf16": 31, "fp16": 32, "fp32": 33}[dtype])
+    tiny = {"bf16": 1e-38, "fp16": 6e-8, "fp32": 1e-42}[dtype]
+    odd_scales = [0.0, tiny, 1e-30, 1e-20, 2.0 ** -60, 2.0 ** -61, 2.0 ** 100, 2.0 ** 101, 1e30, float("inf"), float("nan")]
+    for trial in range(int(os.environ.get("LLMQAT_STRESS_TRIALS", "120")) // 2):
+        rows, cols = int(rng.integers(1, 24)), int(rng.choice([1, 7, 8, 64, 100, 256, 264, 1000, 1024, 4096, 4104, 11008]))
+        w_bits = 1 + trial % 2
+        row_scale = rng.choice([1e-3, 0.02, 1.0, 40.0], size=(rows, 1)).astype(np.float32)
+        w = rng.standard_normal((rows, cols)).astype(np.float32) * row_scale
+        sc = (np.abs(w).mean(axis=1) * (2.0 if w_bits == 2 else 1.0)).astype(np.float32)
+        for r in range(rows):
+            if rng.random() < 0.35:
+                with np.errstate(over="ignore"):
+                    sc[r] = np.float32(rng.choice(odd_scales))
+        sct = torch.from_numpy(sc).to(TD[dtype])                       # the scale is a tensor of the weight's dtype (:205-209)
+        scf = sct.float().numpy()
+        # adversarial elements: signed zeros, specials, denormals, the clamp bounds, quotients far below 1
+        for _ in range(min(12, cols)):
+            r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+            base = scf[r] if np.isfinite(scf[r]) and scf[r] != 0 else 1.0
+            with np.errstate(over="ignore", invalid="ignore"):
+                w[r, c] = np.float32(rng.choice([0.0, -0.0, np.nan, np.inf, -np.inf, tiny, -tiny, 0.99 * base, -0.99 * base, 0.9921875 * base, 0.98828125 * base,
+                                                 0.25 * base, 0.75 * base, -0.25 * base, base * 2.0 ** -120, -base * 2.0 ** -130, base * 1e-30, 3.0 * base]))
+        wt = torch.from_numpy(w).to(TD[dtype]).cuda()
+        w_np = np_from(wt)
+        want, _ = O.w12_fwd(w_np, rows, cols, w_bits, dtype, scale_in=scf)
+        got = pkg.ops.low_bit_weight(wt, sct.cuda(), w_bits)
+        tag = f"trial {trial}: {dtype} [{rows},{cols}] w_bits={w_bits}"
+        assert bits_equal(np_from(got), want, dtype), f"{tag} fq_w12_fwd: {mismatch_report(np_from(got), want, dtype)}"
+        res = pkg.ops.low_bit_weight_fused(wt, w_bits)
+        if res is not None:                                             # the one-launch kernel: ITS scale, the same chain
+            q, s_used = res
+            want2, _ = O.w12_fwd(w_np, rows, cols, w_bits, dtype, scale_in=s_used.float().cpu().numpy())
+            assert bits_equal(np_from(q), want2, dtype), f"{tag} fq_w12_fwd_rows: {mismatch_report(np_from(q), want2, dtype)}"
+
+
 def test_low_bit_fused_row_mean(pkg):
     """the 1-/2-bit branch with the row mean reduced in-kernel (one launch).  Kept OPT-IN: a float sum
     depends on its order, and this test records how far that goes --

@@ -302,6 +302,91 @@ int main(int argc, char** argv) {
     report("write-only 8 B/lane", 1.0 * bytes, time_it([&](int i) {
                hipLaunchKernelGGL(write8_kernel, dim3((unsigned)((2 * nvec + 1023) / 1024)), dim3(256), 0, 0, (uint2*)b.y[i % NS], 2 * nvec);
            }, IT));
+    if (argc > 3 && std::string(argv[3]) == "placement") {
+        // does the DISTANCE between the read stream and the write stream matter (same channel / bank phase)?  src = big, dst = big + D
+        for (int s = 0; s < NS; ++s)
+            printf("separate allocations, set %d: x %p  y %p  (y - x) = %lld B = %.3f MiB, mod 2 MiB = %lld\n", s, b.x[s], b.y[s],
+                   (long long)((char*)b.y[s] - (char*)b.x[s]), ((char*)b.y[s] - (char*)b.x[s]) / 1048576.0,
+                   (long long)(((char*)b.y[s] - (char*)b.x[s]) & ((1 << 21) - 1)));
+        char* big;
+        CK(hipMalloc((void**)&big, (size_t)640 << 20));
+        CK(hipMemset(big, 1, (size_t)640 << 20));
+        const long long MiB = 1 << 20;
+        const long long ds[] = {86 * MiB, 96 * MiB, 128 * MiB, 128 * MiB + 256, 128 * MiB + 4096, 128 * MiB + 65536, 129 * MiB, 130 * MiB, 136 * MiB, 160 * MiB, 192 * MiB,
+                                256 * MiB, 256 * MiB + 4096, 257 * MiB, 384 * MiB, 512 * MiB};
+        for (long long d : ds) {
+            char name[96];
+            snprintf(name, sizeof name, "copy<UNR=1,NT=true> dst = src + %.4f MiB", d / 1048576.0);
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)big, (uint4*)(big + d), nvec);
+                   }, IT));
+        }
+        // is it the SIZE of the allocation (larger physical fragments -> fewer translation misses)?  two separate hipMallocs of S each,
+        // only the first 86 MiB of each used
+        for (long long S : {88 * MiB, 96 * MiB, 128 * MiB, 192 * MiB, 256 * MiB, 512 * MiB, 1024 * MiB}) {
+            char *a, *c;
+            CK(hipMalloc((void**)&a, (size_t)S));
+            CK(hipMalloc((void**)&c, (size_t)S));
+            CK(hipMemset(a, 1, (size_t)S));
+            CK(hipMemset(c, 1, (size_t)S));
+            char name[128];
+            snprintf(name, sizeof name, "copy<UNR=1,NT=true> two hipMallocs of %lld MiB (a %p c %p)", S / MiB, (void*)a, (void*)c);
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)a, (uint4*)c, nvec);
+                   }, IT));
+            CK(hipFree(a));
+            CK(hipFree(c));
+        }
+        // constant vs random data x single pair vs 4 rotating pairs, all freshly allocated 88 MiB buffers
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            char *pa[4], *pc[4];
+            for (int k = 0; k < 4; ++k) {
+                CK(hipMalloc((void**)&pa[k], (size_t)88 << 20));
+                CK(hipMalloc((void**)&pc[k], (size_t)88 << 20));
+                if (rnd) {
+                    hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint16_t*)pa[k], n, 1234u + k, 0.02f);
+                    hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint16_t*)pc[k], n, 4321u + k, 0.02f);
+                } else {
+                    CK(hipMemset(pa[k], 1, (size_t)88 << 20));
+                    CK(hipMemset(pc[k], 1, (size_t)88 << 20));
+                }
+            }
+            CK(hipDeviceSynchronize());
+            char name[128];
+            snprintf(name, sizeof name, "copy NT, fresh 88 MiB buffers, %s data, SINGLE pair", rnd ? "random" : "constant");
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)pa[0], (uint4*)pc[0], nvec);
+                   }, IT));
+            snprintf(name, sizeof name, "copy NT, fresh 88 MiB buffers, %s data, 4 ROTATING pairs", rnd ? "random" : "constant");
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)pa[i % 4], (uint4*)pc[i % 4], nvec);
+                   }, IT));
+            snprintf(name, sizeof name, "copy plain (no NT), fresh buffers, %s data, 4 ROTATING pairs", rnd ? "random" : "constant");
+            report(name, 2.0 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((copy_kernel<1, false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)pa[i % 4], (uint4*)pc[i % 4], nvec);
+                   }, IT));
+            for (int k = 0; k < 4; ++k) { CK(hipFree(pa[k])); CK(hipFree(pc[k])); }
+        }
+        {   // one allocation carved into 8 rotating 88 MiB slots (what a pre-reserved arena would give), rotating like bench.py
+            char* arena;
+            CK(hipMalloc((void**)&arena, (size_t)(8 * 88) << 20));
+            CK(hipMemset(arena, 1, (size_t)(8 * 88) << 20));
+            report("copy<UNR=1,NT=true> ONE 704 MiB arena, 4 rotating (src, dst) slot pairs", 2.0 * bytes, time_it([&](int i) {
+                       const int k = i % 4;
+                       hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0,
+                                          (const uint4*)(arena + (size_t)(2 * k) * (88 << 20)), (uint4*)(arena + (size_t)(2 * k + 1) * (88 << 20)), nvec);
+                   }, IT));
+            CK(hipFree(arena));
+        }
+        // and the same copy between the separately allocated rotating sets (what bench.py's buffers look like)
+        report("copy<UNR=1,NT=true> separate allocations, rotating", 2.0 * bytes, time_it([&](int i) {
+                   hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint4*)b.y[i % NS], nvec);
+               }, IT));
+        report("copy<UNR=1,NT=true> separate allocations, set 0 only", 2.0 * bytes, time_it([&](int i) {
+                   hipLaunchKernelGGL((copy_kernel<1, true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const uint4*)b.x[0], (uint4*)b.y[0], nvec);
+               }, IT));
+        return 0;
+    }
     if (argc > 3 && std::string(argv[3]) == "ceilings") {
         report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
                    hipLaunchKernelGGL((read_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);

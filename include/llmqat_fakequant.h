@@ -39,6 +39,9 @@ extern "C" {
 #define FQ_DTYPE_F32 0
 #define FQ_DTYPE_BF16 1
 #define FQ_DTYPE_F16 2
+/* float64 (the reference has no dtype restriction): a correctness path in double arithmetic, served by fq_sym_fwd / fq_asym_fwd
+ * (+ _debug; no row bounds), fq_ste_bwd and fq_w12_fwd; every other entry point answers FQ_ERR_DTYPE for it. */
+#define FQ_DTYPE_F64 3
 
 /* scalar semantics (only differ for bf16/fp16 rows with |max| < ~4e-5, and Asym fp32 `.div(S)`) */
 #define FQ_SEM_CPU_EAGER 0    /* canonical: what ATen's CPU kernels do; pinned by tests/golden */

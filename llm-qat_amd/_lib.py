@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libllmqat_fakequant.so")
 ABI_VERSION = 3
 
-DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
 SEM_CPU_EAGER, SEM_DEVICE_EAGER = 0, 1
 
 # every symbol include/llmqat_fakequant.h declares (tests check the .so exports them all)

@@ -41,13 +41,17 @@ struct MaskArgs {
 template <bool ASYM>
 int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, int64_t rows, int64_t cols, int bits, int dtype,
             int sem, void* ws, size_t wsb, void* stream, const MaskArgs* mk = nullptr) {
-    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (dtype < 0 || dtype > FQ_DTYPE_F64) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (bits < (ASYM ? 1 : 2) || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [%d, 31]", bits, ASYM ? 1 : 2);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape rows=%lld cols=%lld", (long long)rows, (long long)cols);
     if (rows == 0 || cols == 0) return ok();  // empty tensor: nothing to do (the reference returns an empty tensor)
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
+    if (dtype == FQ_DTYPE_F64) {  // correctness path in double arithmetic; no training-mode side buffers
+        if (bounds || mk) return fail(FQ_ERR_DTYPE, "float64 tensors: row bounds / STE mask are not produced (use fq_ste_bwd, the reference's data flow)");
+        return launch_f64_rowwise(ASYM, x, y, idx, scale, rows, cols, bits, sem, (hipStream_t)stream);
+    }
     const Consts c = make_consts(bits, dtype, sem);
     RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, 0u, rows, 0, {}};
     if (mk) {
@@ -263,11 +267,12 @@ FQ_API int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, 
 
 FQ_API int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                       int dtype, void* stream) {
-    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (dtype < 0 || dtype > FQ_DTYPE_F64) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (w_bits != 1 && w_bits != 2) return fail(FQ_ERR_BITS, "w_bits=%d: this entry point serves 1 and 2", w_bits);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
     if (rows == 0 || cols == 0) return ok();
     if (!w || !scale || !out) return fail(FQ_ERR_NULL, "w / scale / out must not be NULL");
+    if (dtype == FQ_DTYPE_F64) return launch_f64_w12(w, scale, out, rows, cols, w_bits, scale_per_row, (hipStream_t)stream);
     // clip_val = 1 - 1e-2 (utils_quant.py:217): a Python double; the clamp compares in fp32 on the device and in the
     // tensor dtype on the CPU -- both give the same results (DESIGN.md "Numerics"), fp32 is used here
     const float cv = (float)(1.0 - 1e-2);
@@ -296,10 +301,11 @@ FQ_API int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t ro
 }
 
 FQ_API int fq_ste_bwd(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, int dtype, void* stream) {
-    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (dtype < 0 || dtype > FQ_DTYPE_F64) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (n < 0) return fail(FQ_ERR_SHAPE, "negative n");
     if (n == 0) return ok();
     if (!g || !x || !gx) return fail(FQ_ERR_NULL, "g / x / gx must not be NULL");
+    if (dtype == FQ_DTYPE_F64) return launch_f64_ste(g, x, gx, n, lo, hi, (hipStream_t)stream);  // the clip is a float32 tensor (:198,:245): its values as doubles
     lo = host_rb(lo, dtype);  // the reference compares in the tensor dtype (utils_quant.py:85-86)
     hi = host_rb(hi, dtype);
     hipStream_t st = (hipStream_t)stream;

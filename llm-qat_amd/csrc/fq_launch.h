@@ -140,7 +140,12 @@ inline Consts make_consts(int bits, int dt, int sem) {
     return c;
 }
 
-inline int esize_of(int dtype) { return dtype == FQ_DTYPE_F32 ? 4 : 2; }
+inline int esize_of(int dtype) { return dtype == FQ_DTYPE_F64 ? 8 : dtype == FQ_DTYPE_F32 ? 4 : 2; }
+
+// float64 tensors (fq_f64.hip): a correctness path in double arithmetic
+FQ_HIDDEN int launch_f64_rowwise(bool asym, const void* x, void* y, int32_t* idx, float* scale, int64_t rows, int64_t cols, int bits, int sem, hipStream_t st);
+FQ_HIDDEN int launch_f64_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st);
+FQ_HIDDEN int launch_f64_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, hipStream_t st);
 
 
 template <int DT> FQ_HIDDEN int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, size_t wsb, hipStream_t st);

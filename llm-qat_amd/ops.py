@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16, torch.float64: _lib.DTYPE_F64}
 _SEM_NAMES = {"cpu_eager": _lib.SEM_CPU_EAGER, "device_eager": _lib.SEM_DEVICE_EAGER}
 _semantics = _SEM_NAMES[os.environ.get("LLMQAT_AMD_SEMANTICS", "cpu_eager")]
 
@@ -51,7 +51,7 @@ def _prep(x, what):
                            "fallback; move the tensor to the GPU (or use the reference implementation on CPU).")
     code = _DTYPES.get(x.dtype)
     if code is None:
-        raise NotImplementedError(f"{what}: dtype {x.dtype} is not supported (float32, bfloat16, float16 are)")
+        raise NotImplementedError(f"{what}: dtype {x.dtype} is not supported (float32, bfloat16, float16, float64 are)")
     return code
 
 
@@ -108,6 +108,8 @@ def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     ws_ptr = ws.data_ptr() if ws is not None else None
     bounds = idx = scale = None
+    if code == _lib.DTYPE_F64:
+        want_bounds = False   # float64: a correctness path without training-mode side buffers (the backward re-reads x)
     with _DeviceOf(x):
         if debug:
             idx = torch.empty(xc.shape, dtype=torch.int32, device=x.device)

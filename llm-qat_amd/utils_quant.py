@@ -91,7 +91,7 @@ class _FakeQuantFunction(torch.autograd.Function):
             return ops.sym_quantize(input, num_bits, layerwise) if kind == "sym" else ops.asym_quantize(input, num_bits, layerwise)
         if kind == "sym" and ops.autocast_active(input):
             return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
-        mode = _BACKWARD_MODE
+        mode = "plain" if input.dtype == torch.float64 else _BACKWARD_MODE   # float64: the reference's data flow (saved input)
         ctx.fq_mode = "plain"
         if mode == "mask":
             lo, hi = _clip_pair(clip_val)

@@ -18,8 +18,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "fq_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("fq_oracle.c", "fq_oracle_f64.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libfq_oracle.so"])
     return _LIB_PATH
 
@@ -39,12 +39,18 @@ def lib():
         L.fqo_export.restype = ctypes.c_int
         for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version, L.fqo_sym_fwd_autocast):
             f.restype = ctypes.c_int
+        L.fqo64_sym_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32]
+        L.fqo64_asym_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32]
+        L.fqo64_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32]
+        L.fqo64_w12_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32]
+        for f in (L.fqo64_sym_fwd, L.fqo64_asym_fwd, L.fqo64_ste_bwd, L.fqo64_w12_fwd):
+            f.restype = ctypes.c_int
         _lib = L
     return _lib
 
 
 def _check(x, dtype):
-    want = np.float32 if dtype == "fp32" else np.uint16
+    want = np.float64 if dtype == "fp64" else np.float32 if dtype == "fp32" else np.uint16
     if x.dtype != want:
         raise TypeError(f"{dtype} data must be {want}, got {x.dtype}")
     return np.ascontiguousarray(x)
@@ -60,6 +66,12 @@ def sym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
     assert x.size == rows * cols
     y = np.empty_like(x)
     idx = np.empty(x.shape, np.int32) if want_idx else None
+    if dtype == "fp64":   # fq_oracle_f64.c: every op in double (sem does not matter for Sym); the scale comes back as float64
+        scale = np.empty(rows, np.float64)
+        rc = lib().fqo64_sym_fwd(_p(x), _p(y), _p(idx), _p(scale), rows, cols, bits)
+        if rc:
+            raise ValueError(f"fqo64_sym_fwd rc={rc}")
+        return y, idx, scale
     scale = np.empty(rows, np.float32)
     rc = lib().fqo_sym_fwd(_p(x), _p(y), _p(idx), _p(scale), rows, cols, bits, DTYPES[dtype], sem)
     if rc:
@@ -84,6 +96,12 @@ def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
     assert x.size == rows * cols
     y = np.empty_like(x)
     idx = np.empty(x.shape, np.int32) if want_idx else None
+    if dtype == "fp64":
+        alpha, beta = np.empty(rows, np.float64), np.empty(rows, np.float64)
+        rc = lib().fqo64_asym_fwd(_p(x), _p(y), _p(idx), _p(alpha), _p(beta), rows, cols, bits, sem)
+        if rc:
+            raise ValueError(f"fqo64_asym_fwd rc={rc}")
+        return y, idx, alpha, beta
     alpha = np.empty(rows, np.float32)
     beta = np.empty(rows, np.float32)
     rc = lib().fqo_asym_fwd(_p(x), _p(y), _p(idx), _p(alpha), _p(beta), rows, cols, bits, DTYPES[dtype], sem)
@@ -130,6 +148,11 @@ def ste_bwd(g, x, lo, hi, dtype):
     g, x = _check(g, dtype), _check(x, dtype)
     assert g.size == x.size
     gx = np.empty_like(g)
+    if dtype == "fp64":
+        rc = lib().fqo64_ste_bwd(_p(g), _p(x), _p(gx), g.size, lo, hi)
+        if rc:
+            raise ValueError(f"fqo64_ste_bwd rc={rc}")
+        return gx
     rc = lib().fqo_ste_bwd(_p(g), _p(x), _p(gx), g.size, lo, hi, DTYPES[dtype])
     if rc:
         raise ValueError(f"fqo_ste_bwd rc={rc}")
@@ -140,6 +163,13 @@ def w12_fwd(w, rows, cols, w_bits, dtype, scale_in=None):
     """1-/2-bit weight branch of QuantizeLinear -> (q, scale[rows])"""
     w = _check(w, dtype)
     q = np.empty_like(w)
+    if dtype == "fp64":
+        sc = np.empty(rows, np.float64)
+        si = None if scale_in is None else np.ascontiguousarray(scale_in, np.float64)
+        rc = lib().fqo64_w12_fwd(_p(w), _p(q), _p(sc), _p(si), rows, cols, w_bits)
+        if rc:
+            raise ValueError(f"fqo64_w12_fwd rc={rc}")
+        return q, sc
     sc = np.empty(rows, np.float32)
     si = None if scale_in is None else np.ascontiguousarray(scale_in, np.float32)
     rc = lib().fqo_w12_fwd(_p(w), _p(q), _p(sc), _p(si), rows, cols, w_bits, DTYPES[dtype])

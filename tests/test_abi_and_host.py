@@ -52,7 +52,8 @@ def test_argument_validation_without_gpu():
     assert L.fq_last_error() == b""
     assert L.fq_ste_bwd(None, None, None, 0, -2.0, 2.0, 1, None) == 0
     assert L.fq_ste_bwd(None, None, None, 8, -2.0, 2.0, 1, None) == -4
-    assert L.fq_ste_bwd(None, None, None, 8, -2.0, 2.0, 3, None) == -1
+    assert L.fq_ste_bwd(None, None, None, 8, -2.0, 2.0, 4, None) == -1      # (3 = float64 is served since round 3)
+    assert L.fq_ste_bwd_rows(None, None, None, 2, 4, -2.0, 2.0, None, 3, None) == -1   # float64: no training-mode side buffers
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
     assert L.fq_sym_fwd(p, p, 1, 8, 4, 1, 0, None, None, 0, None) == -7            # in-place rejected

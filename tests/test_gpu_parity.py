@@ -295,8 +295,10 @@ def test_error_behaviour_matches_reference(ops):
     SymQuantizer.apply(torch.zeros(1, 1, 1, 1, 2, device="cuda"), clip, 8, True)   # layerwise accepts any rank
     with pytest.raises(RuntimeError):    # no CPU fallback
         SymQuantizer.apply(torch.zeros(4, 4), clip, 8, False)
+    z64 = SymQuantizer.apply(torch.zeros(4, 4, device="cuda", dtype=torch.float64), clip, 8, False)   # float64 is served since round 3 (tests/test_f64.py)
+    assert z64.dtype == torch.float64 and not z64.any()
     with pytest.raises(NotImplementedError):
-        SymQuantizer.apply(torch.zeros(4, 4, device="cuda", dtype=torch.float64), clip, 8, False)
+        SymQuantizer.apply(torch.zeros(4, 4, device="cuda", dtype=torch.int32), clip, 8, False)
     e = SymQuantizer.apply(torch.zeros(0, 8, device="cuda"), clip, 8, False)
     assert e.shape == (0, 8)
     z = SymQuantizer.apply(torch.tensor(1.5, device="cuda"), clip, 8, False)      # 0-dim: one row of one element

@@ -158,7 +158,7 @@ class SymQuantizer(_FakeQuantFunction):
     @classmethod
     def apply(cls, input, clip_val, num_bits, layerwise):
         # the unchanged KV-cache hooks (two consecutive apply calls on k_proj's and v_proj's outputs): one launch, see point 7
-        if _PAIR_KV and cls is SymQuantizer and not layerwise:
+        if _PAIR_KV and cls is SymQuantizer and not layerwise and not torch._C._are_functorch_transforms_active():
             out = _kv_hook(input, clip_val, num_bits)
             if out is not None:
                 return out

@@ -45,11 +45,24 @@ def get_backward_mode():
     return _BACKWARD_MODE
 
 
+_clip_memo = {}
+
+
 def _clip_pair(clip_val):
+    """(lo, hi) of a clip tensor as Python floats.  The model keeps its clip tensors alive (act_clip_val_k / _v are attributes,
+    modeling_llama_quant.py:251-252), so the host read is memoised per tensor object and version (a weak reference guards id reuse)."""
     if clip_val is _CLIP:
         return -2.0, 2.0
+    ent = _clip_memo.get(id(clip_val))
+    if ent is not None and ent[0]() is clip_val and ent[1] == clip_val._version:
+        return ent[2]
     lo, hi = clip_val.tolist()[:2] if clip_val.dim() else (clip_val.item(),) * 2
-    return float(lo), float(hi)
+    pair = (float(lo), float(hi))
+    if clip_val.device.type == "cpu":   # (a device tensor's .tolist() synchronises; do not hide that by caching across in-place updates we cannot see coming)
+        if len(_clip_memo) > 64:
+            _clip_memo.clear()
+        _clip_memo[id(clip_val)] = (weakref.ref(clip_val), clip_val._version, pair)
+    return pair
 
 
 class _FakeQuantFunction(torch.autograd.Function):

@@ -1158,6 +1158,16 @@ def test_inplace_ste_backward_kernel(pkg):
             assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
             ref = torch.where((x >= 2) | (x <= -2), torch.zeros_like(g), g)
             assert torch.equal(got, ref)
+    # rows long enough for two chunks per row (grid y = 2), 1 to 600 rows (in-place blocks cover 256 rows each), clippable rows at block edges
+    for rows_, cols_ in ((1, 32768), (255, 32768), (257, 24576), (600, 32768)):
+        x = (torch.randn(rows_, cols_, generator=g0, device="cuda") * 0.02).bfloat16()
+        for r in sorted({0, rows_ // 2, rows_ - 1, min(255, rows_ - 1), min(256, rows_ - 1)}):
+            x[r, 5], x[r, cols_ - 3], x[r, cols_ // 2 + 1] = 2.0, -2.5, 3.0
+        y, side, rows, cols = ops.train_forward("sym", x, 4, False, -2.0, 2.0)
+        g = torch.randn(rows_, cols_, generator=g0, device="cuda").bfloat16()
+        ref = torch.where((x >= 2) | (x <= -2), torch.zeros_like(g), g)
+        gi = g.clone()
+        assert torch.equal(ops.train_backward(gi, side, rows, cols, -2.0, 2.0, inplace=True), ref) and torch.equal(ops.train_backward(g, side, rows, cols, -2.0, 2.0), ref)
     # pair + multi launches: the weight slots in place, the activation slot to a fresh tensor
     xs = (torch.randn(64, 2048, generator=g0, device="cuda") * 1.3).bfloat16()
     w2 = (torch.randn(128, 2048, generator=g0, device="cuda") * 0.02).bfloat16()

@@ -3,13 +3,15 @@
   * shared activation quant for sibling projections; weight-quant reuse across checkpoint recompute
   * hipGraph capture of the C-ABI calls; use from several streams and from the autograd thread
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
-from conftest import bits_equal, golden, mismatch_report, to_f32
+from conftest import ROOT, bits_equal, golden, mismatch_report, to_f32
 from oracle import oracle as O
 from test_gpu_parity import TD, dev_from, np_from
 
@@ -709,6 +711,39 @@ def test_fsdp_wrapped_model_step_is_unchanged(pkg, wcache):
             assert torch.equal(got[n].view_as(want[n]), want[n]), n
     finally:
         dist.destroy_process_group()
+
+
+def test_two_rank_fsdp_full_shard_with_checkpointing(pkg, tmp_path):
+    """the reference's real configuration -- FSDP `full_shard auto_wrap` per decoder layer + NON-reentrant gradient
+    checkpointing + bf16 autocast (run_train.sh:17-18,:36,:42-43) -- on TWO ranks (fresh child processes, both on this GPU, gloo
+    collectives): flat parameters are really sharded, all-gathered before every layer forward / recompute / backward and freed after.
+    Three optimizer steps: every step's loss and every parameter afterwards are bit-identical between the reference's eager op chain
+    and the drop-in (default settings, the weight cache, and the opt-in sibling groups, whose activation is version-gated)."""
+    import socket
+    import subprocess
+    import sys
+    res = {}
+    for impl in ("eager", "ours", "ours_wcache", "ours_groups"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"{impl}.pt")
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fsdp_worker.py"), impl, out], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        logs = [p.communicate(timeout=420) for p in procs]
+        assert all(p.returncode == 0 for p in procs), (impl, [lg[1][-1500:] for lg in logs])
+        res[impl] = torch.load(out, weights_only=True)
+    ref = res["eager"]
+    assert torch.isfinite(ref["losses"]).all() and ref["losses"][0] != ref["losses"][2]
+    for impl in ("ours", "ours_wcache", "ours_groups"):
+        got = res[impl]
+        assert torch.equal(got["losses"], ref["losses"]), (impl, got["losses"], ref["losses"])
+        assert set(got["params"]) == set(ref["params"])
+        for n in ref["params"]:
+            assert torch.equal(got["params"][n], ref["params"][n]), (impl, n)
 
 
 def test_ddp_wrapped_model_step_is_unchanged(pkg):

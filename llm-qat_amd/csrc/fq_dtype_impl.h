@@ -3,12 +3,15 @@
 #include "../../include/llmqat_fakequant.h"
 #include "fq_launch.h"
 
+
 namespace fq {
 
 #define FQ_LAUNCH(kern, grid, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, st, __VA_ARGS__)
 
 // Launch shape of the register-resident kernel, from tools/kbench on MI355X: 2-3 vectors per
-// thread is the sweet spot (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
+// thread is the sweet spot (round 3 re-checked with block sizes that are not powers of two -- 704 x 2 for 11008 cols wastes 2 % of
+// the vector slots instead of 10 %, 576 x 3 for 13824, 320 x 2 for 5120 -- and with 256 x 6 for mid-sized tensors: within +-2 % of
+// the shapes below everywhere, profiles/r03_kbench_block_shapes.txt, r03_ab_mid_rows_256.txt) (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
 // 4096 cols: 256 x 2 = 6.1 us, 128 x 4 = 6.3, 64 x 8 = 6.9, 512 x 1 = 7.7).
 template <int DT, bool ASYM, bool FAST, bool NTL, bool NTS, bool DBG>
 static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {

@@ -416,6 +416,11 @@ int main(int argc, char** argv) {
     SYM(512, 3, true, false, false) SYM(512, 3, true, true, true) SYM(1024, 2, true, true, true) SYM(256, 6, false, true, true)
     SYM(256, 2, true, false, false) SYM(256, 2, true, true, true) SYM(256, 2, true, true, false) SYM(256, 2, true, false, true) SYM(128, 4, true, true, true) SYM(64, 8, true, true, true) SYM(512, 1, true, true, true)
     SYM(256, 7, true, true, true) SYM(512, 4, true, true, true)
+    // block sizes that are not powers of two: fewer idle vector slots (11008 cols = 1376 vectors: 704 x 2 = 1408 vs 512 x 3 = 1536;
+    // 13824 cols = 1728 vectors: 576 x 3 exactly vs 512 x 4 = 2048; 5120 cols = 640 vectors: 320 x 2 exactly vs 256 x 3 = 768)
+    SYM(704, 2, true, true, true) SYM(704, 2, true, false, true) SYM(576, 3, true, true, true) SYM(320, 2, true, true, true) SYM(320, 2, true, false, true)
+    SYM(256, 3, true, true, true) SYM(256, 3, true, false, true) SYM(896, 2, true, true, true) SYM(448, 4, true, true, true) SYM(640, 3, true, true, true)
+    if (argc > 3 && std::string(argv[3]) == "shapes") return 0;
 
     // ---- full launch-shape sweep: every TPR whose VPT = ceil(nvec/TPR) fits in 1..8
     if (argc > 3) {

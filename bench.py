@@ -20,10 +20,10 @@ the same step on its own GPU, no data-path collective; value = N * per-rank elem
 anything touches a GPU; under `python -m torch.distributed.run` it joins the ranks the launcher started.
 A request for N ranks never reports fewer: if a rank is missing the run exits non-zero.
 
-Output (round 3): the LAST stdout line is a compact headline (< 4 KB: the contract's keys + `roofline`, `roofline_step`,
+Output (round 3): stdout carries exactly ONE line, a compact headline (< 4 KB: the contract's keys + `roofline`, `roofline_step`,
 `cpu_baseline`, `value_out_of_place`) -- the driver keeps an 8 KB stdout tail, and round 2's single 27 KB line was cut.
-Every other family below is printed as its own earlier stdout line ({"bench_extras": <family>, "data": ...}) and the whole
-record is written to bench_extras.json next to this file.
+Every other family below is printed as its own STDERR line ({"bench_extras": <family>, "data": ...}) and the whole record is
+written to bench_extras.json next to this file.
 Families (every `frac` is a byte RATE the kernel sustained / 8 TB/s, never > 1):
   roofline      dominant kernel (the step's forward launch): algorithmic bytes / live HIP-event launch time vs 8 TB/s
   kernels_step  both launches of the step;  kernels  the four single-tensor launches
@@ -1036,8 +1036,8 @@ def compact_headline(out, extras_file=None):
 
 
 def emit(out, args):
-    """full record -> bench_extras.json (next to bench.py, and gpurun_out/ when that exists) + one earlier stdout line per extras
-    family; then the compact headline as the LAST stdout line."""
+    """full record -> bench_extras.json (next to bench.py, and gpurun_out/ when that exists) + one STDERR line per extras family;
+    stdout carries exactly ONE line, the compact headline (the launch contract: "rank 0 prints ONE JSON line")."""
     head_keys = set(_HEAD_KEYS) | {"config", "roofline", "roofline_step", "cpu_baseline", "hbm_gbs_note"}
     extras_file = None
     if not getattr(args, "no_sidecar", False):
@@ -1046,12 +1046,12 @@ def emit(out, args):
                 if os.path.isdir(d):
                     with open(os.path.join(d, "bench_extras.json"), "w") as f:
                         json.dump(out, f, indent=1)
-                    extras_file = extras_file or "bench_extras.json (next to bench.py; the same families are the stdout lines above this one)"
+                    extras_file = extras_file or "bench_extras.json (next to bench.py; the same families are printed on stderr)"
             except OSError:
                 pass
     for k, v in out.items():
         if k not in head_keys:
-            print(json.dumps({"bench_extras": k, "data": v}), flush=True)
+            print(json.dumps({"bench_extras": k, "data": v}), file=sys.stderr, flush=True)
     print(compact_headline(out, extras_file), flush=True)
 
 

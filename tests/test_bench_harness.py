@@ -165,16 +165,19 @@ def test_headline_stays_compact_whatever_the_extras_grow_to():
     assert len(bench.compact_headline(full, "x").encode()) < 4096
 
 
-def test_emit_prints_extras_first_and_the_headline_last(capsys):
+def test_emit_prints_one_stdout_line_and_the_extras_on_stderr(capsys):
     import argparse
     full = _full_record()
     bench.emit(full, argparse.Namespace(no_sidecar=True))
-    lines = capsys.readouterr().out.strip().splitlines()
-    assert len(lines) > 5 and all(json.loads(ln).get("bench_extras") for ln in lines[:-1])
-    fams = {json.loads(ln)["bench_extras"] for ln in lines[:-1]}
+    cap = capsys.readouterr()
+    lines = cap.out.strip().splitlines()
+    assert len(lines) == 1, "stdout must carry exactly ONE JSON line (the launch contract)"
+    last = json.loads(lines[0])
+    assert len(lines[0].encode()) < 4096 and "bench_extras" not in last and last["value"] == full["value"]
+    extras = cap.err.strip().splitlines()
+    assert len(extras) > 5 and all(json.loads(ln).get("bench_extras") for ln in extras)
+    fams = {json.loads(ln)["bench_extras"] for ln in extras}
     assert {"kernels", "kernels_step", "kernels_model_shapes", "kernels_export", "gpu_eager"} <= fams
-    last = json.loads(lines[-1])
-    assert len(lines[-1].encode()) < 4096 and "bench_extras" not in last and last["value"] == full["value"]
 
 
 def test_stub_line_is_compact_too():

@@ -39,10 +39,11 @@ def short(name):
 
 
 def rows_of(path, pattern):
-    out = []
-    for f in sorted(glob.glob(os.path.join(path, "*", pattern))):
-        out += list(csv.DictReader(open(f)))
-    return out
+    """the newest file of this kind in the pass's directory (gpurun merges a re-run's files next to an earlier run's: one process = one file)"""
+    files = glob.glob(os.path.join(path, "*", pattern))
+    if not files:
+        return []
+    return list(csv.DictReader(open(max(files, key=os.path.getmtime))))
 
 
 def fq_dispatches(path, counters):
@@ -119,10 +120,10 @@ def main():
 
     # 0. rocprofv3 --stats summaries, per kernel name (as rocprofv3 prints them)
     for sub, dst, cmd in (("trace", f"{tag}_kernel_stats.csv", cmd_step), ("ms_trace", f"{tag}_model_shapes_kernel_stats.csv", cmd_ms)):
-        files = sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")))
+        files = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
         if not files:
             continue
-        rows = list(csv.DictReader(open(files[0])))
+        rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))
         with open(os.path.join(out, dst), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow([f"# rocprofv3 --kernel-trace --stats -- {cmd}  (MI355X, gfx950)"])

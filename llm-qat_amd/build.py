@@ -25,7 +25,7 @@ def up_to_date():
 
 
 def build_extension(force=False, verbose=False, extra_flags=(), out=None):
-    """extra_flags / out: A/B builds of kernel variants for tools/ab_bench.sh (e.g. -DFQ_MASK_FETCH_BYTES=1 -> another .so);
+    """extra_flags / out: A/B builds of kernel variants for tools/ab_bench.sh (e.g. -DSOME_VARIANT=1 --out=build_tmp/lib_b.so);
     the product build takes neither."""
     if out is None and not force and up_to_date():
         return LIB

@@ -33,7 +33,6 @@ struct ExportArgs {
     AsymConst asym;
     int container;
     int autocast;        // Sym on 16-bit tensors: the reference's arithmetic under CUDA autocast (fp32 behind the reciprocal)
-    int wide_st;         // bin rows are 16-byte aligned (bins base and row stride): 16-byte stores after a lane exchange
     float cmin, cmax;    // container range as floats: Sym signed [-2^(b-1), 2^(b-1)-1], Asym unsigned [0, 2^b - 1]
 };
 
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
                 nbad += (bad && v < nvec) ? 1u : 0u;  // (a ballot + popcount per element made these rows ~10x slower than the others)
             }
         }
-        // pack this slot's bins; the stores follow the loop (lanes trade packed dwords so that each store is 16 bytes)
+        // pack this slot's bins; the stores follow the loop
         if (cont == BINS_INT8) {
 #pragma unroll
             for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
@@ -231,56 +230,21 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
             for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm((uint32_t)q[2 * d + 1], (uint32_t)q[2 * d], 0x05040100u);
         }
     }
-    // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16.  Writing 8 or 4
-    // bytes per lane makes every wave-instruction cover half / a quarter of each 128-byte line (int8 26.5 us, int4 22.6 us on
-    // [4096,11008] bf16 in round 2), so neighbouring lanes trade dwords first: lane pairs over two slots (8-byte vectors) or
-    // quads over four slots (4-byte vectors), and every storing lane writes 16 contiguous bytes of one slot.  Needs 16-byte
-    // aligned bin rows (a.wide_st, decided on the host; whole pairs / quads of vectors then exist); otherwise the narrow stores.
+    // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16, else 8, 4 or 2.  Round 3
+    // built the alternative -- lane pairs / quads trade packed dwords over two / four slots so that every storing lane writes 16
+    // bytes -- and measured it against these plain stores on one box (profiles/r03_ab_export_store_width.txt): int4 22.22 vs 22.23 us,
+    // int8 25.1-25.6 vs 25.7-27.4 us.  The store width is not what keeps these kernels above their streaming ceilings, so the simple
+    // form stays.
     if (cont != BINS_NONE) {
         const int vb = cont == BINS_INT4 ? EPV / 2 : cont == BINS_INT8 ? EPV : 2 * EPV;  // bytes per vector
-        if (vb == 16) {
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const int v = t + i * TPR;
-                if (v < nvec) st16<true>((uint4*)brow + v, make_uint4(pk[i][0], pk[i][1], pk[i][2], pk[i][3]));
-            }
-        } else if (vb == 8 && a.wide_st) {
-            const bool odd = t & 1;
-#pragma unroll
-            for (int i = 0; i < VPT; i += 2) {
-                if (i + 1 < VPT) {  // even lanes finish slot i, odd lanes slot i + 1
-                    const uint32_t r0 = dpp<0xB1>(odd ? pk[i][0] : pk[i + 1][0]), r1 = dpp<0xB1>(odd ? pk[i][1] : pk[i + 1][1]);
-                    const uint4 o = odd ? make_uint4(r0, r1, pk[i + 1][0], pk[i + 1][1]) : make_uint4(pk[i][0], pk[i][1], r0, r1);
-                    const int v = odd ? t + (i + 1) * TPR : t + i * TPR;
-                    if (v < nvec) st16<true>((uint4*)(brow + (int64_t)(v & ~1) * 8), o);
-                } else {            // odd slot count: the last slot is finished by the even lanes alone
-                    const uint32_t r0 = dpp<0xB1>(pk[i][0]), r1 = dpp<0xB1>(pk[i][1]);
-                    const int v = t + i * TPR;
-                    if (!odd && v < nvec) st16<true>((uint4*)(brow + (int64_t)v * 8), make_uint4(pk[i][0], pk[i][1], r0, r1));
-                }
-            }
-        } else if (vb == 4 && a.wide_st) {
-            const bool l1 = t & 1, l2 = t & 2;
-#pragma unroll
-            for (int i = 0; i < VPT; i += 4) {  // 4 x 4 transpose inside each quad: lane j of the quad finishes slot i + j
-                const uint32_t m0 = pk[i][0], m1 = pk[i + 1 < VPT ? i + 1 : i][0], m2 = pk[i + 2 < VPT ? i + 2 : i][0], m3 = pk[i + 3 < VPT ? i + 3 : i][0];
-                const uint32_t ra = dpp<0xB1>(l1 ? m0 : m1), rb = dpp<0xB1>(l1 ? m2 : m3);
-                const uint32_t a0 = l1 ? ra : m0, a1 = l1 ? m1 : ra, b0 = l1 ? rb : m2, b1 = l1 ? m3 : rb;
-                const uint32_t r0 = dpp<0x4E>(l2 ? a0 : b0), r1 = dpp<0x4E>(l2 ? a1 : b1);
-                const uint4 o = l2 ? make_uint4(r0, r1, b0, b1) : make_uint4(a0, a1, r0, r1);
-                const int slot = i + (t & 3);
-                const int vq = (t & ~3) + slot * TPR;  // first vector of this quad in that slot
-                if (slot < VPT && vq < nvec) st16<true>((uint4*)(brow + (int64_t)vq * 4), o);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const int v = t + i * TPR;
-                if (v >= nvec) continue;
-                if (vb == 8) st8<true>((uint2*)brow + v, make_uint2(pk[i][0], pk[i][1]));
-                else if (vb == 4) __builtin_nontemporal_store(pk[i][0], (uint32_t*)brow + v);
-                else __builtin_nontemporal_store((uint16_t)pk[i][0], (uint16_t*)brow + v);
-            }
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * TPR;
+            if (v >= nvec) continue;
+            if (vb == 16) st16<true>((uint4*)brow + v, make_uint4(pk[i][0], pk[i][1], pk[i][2], pk[i][3]));
+            else if (vb == 8) st8<true>((uint2*)brow + v, make_uint2(pk[i][0], pk[i][1]));
+            else if (vb == 4) __builtin_nontemporal_store(pk[i][0], (uint32_t*)brow + v);
+            else __builtin_nontemporal_store((uint16_t)pk[i][0], (uint16_t*)brow + v);
         }
     }
     if (a.overflow) {

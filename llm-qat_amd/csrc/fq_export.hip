@@ -75,7 +75,6 @@ int export_entry(const void* x, void* bins, float* scales, int32_t* overflow, in
     a.rows = rows;
     a.cols = cols;
     a.row_bytes = export_row_bytes(cols, container);
-    a.wide_st = (aligned16(bins) && a.row_bytes % 16 == 0) ? 1 : 0;
     a.sym = c.sym;
     a.asym = c.asym;
     a.container = container;

@@ -752,7 +752,7 @@ def test_ste_mask_is_the_documented_row_bitmap(ops, dtype):
     st = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(79)
     inf = float("inf")
-    clips = ((-2.0, 2.0), (-0.5, 0.75), (-0.3009, 0.3009), (-inf, inf), (-0.0, 0.0), (-1e-3, 1e-3))
+    clips = ((-2.0, 2.0), (-0.5, 0.75), (-0.3009, 0.3009), (-inf, inf), (-0.0, 0.0), (-1e-3, 1e-3), (-6e-8, 6e-8), (-7e4, 7e4))   # (fp16: subnormal / overflowing clip)
     shapes = ((6, 4), (5, 12), (5, 8), (4, 264), (5, 520), (4, 4096), (4, 11008)) if dtype == "fp32" else ((5, 8), (6, 24), (4, 264), (5, 520), (4, 4096), (4, 11008))
 
     def expected(x_np, rows, cols, lo, hi):

@@ -169,6 +169,21 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         if (t == 0 && a.overflow) a.overflow[row] = 0;
         return;  // the scale pre-pass: nothing elementwise to do
     }
+    // How a row's bins become integers (block-uniform):
+    //   0  the row's top bin fits the container, so every bin does and none is NaN: the integer comes out of ONE add --
+    //      p + 1.5 * 2^23 rounds p to an integer (half to even, like torch.round) and leaves its two's complement in the low
+    //      mantissa bits (|p| < 2^22 holds for every container);
+    //   1  the top bin is finite but does not fit (a bf16 8-bit row whose top bin is +128, 16-bit bins into int8, ...): p is an
+    //      ordinary number everywhere in the row, so v_med3_f32 clamps the sum behind the same add and a compare counts what moved;
+    //   2  NaN / Inf / huge rows: saturate and count element by element (sat_bin).
+    const int mode = !count ? 0 : (top < 4194304.0f ? 1 : 2);
+    // int4: nibbles are built in offset binary (bin - cmin in 0..15, so neighbours cannot borrow from each other) with shift-adds
+    // on the raw sums and flipped to two's complement by one XOR per stored dword.  The offset rides in the rounding constant (an
+    // even integer: ties still go to even).
+    const int ibias = cont == BINS_INT4 ? -(int)a.cmin : 0;
+    const float magic = 12582912.0f + (float)ibias;
+    const uint32_t flip = ibias ? 0x88888888u : 0u;
+    constexpr uint32_t MAGIC_U = 0x4B400000u;  // bits of 1.5 * 2^23
     char* brow = (char*)a.bins + row * a.row_bytes;
     uint32_t nbad = 0;  // per lane; summed over the wave after the loop
     uint32_t pk[VPT][4] = {};  // this lane's packed bins per slot (EPV * container bits / 32 dwords used)
@@ -186,29 +201,61 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         }
         if (want_mask) ste_mask_record<DT>(mrow, v, v < nvec, r[i], f, a.lo, a.hi, sym_clip, clipk);
         if (cont == BINS_NONE) continue;
-        int q[EPV];
-        if (!count) {
-            // Fast path (block-uniform): the row's top bin fits the container, so every bin does and none is NaN.  The
-            // integer comes out of ONE add: p + 1.5 * 2^23 rounds p to an integer (half to even, like torch.round) and
-            // leaves its two's complement in the low mantissa bits (|p| < 2^22 holds for every container).
+        uint32_t qu[EPV];  // MAGIC_U + ibias + bin
+        if (mode < 2) {
+            // p = what torch.round() sees, dword by dword so that the multiplies, roundings and the final add pair up
+            // (v_pk_mul_f32, ONE v_cvt_pk_bf16_f32 per pair, v_pk_add_f32); the autocast switch is taken once per slot
+            if constexpr (ASYM) {
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                float p;
-                if constexpr (ASYM) {
-                    const float d = T::rb(f[e] - ar.mn);
-                    const float n = T::rb(ar.mk ? div_exact(d, ar.a, ar.ra) : d / ar.a);
-                    p = T::rb(n * a.asym.S);
-                } else {
-                    p = ac ? f[e] * sr.s : T::rb(f[e] * sr.s);
+                for (int d = 0; d < 4; ++d) {
+                    float g[T::EPD];
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] - ar.mn;
+                    T::round_dt(g);
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) g[k] = ar.mk ? div_exact(g[k], ar.a, ar.ra) : g[k] / ar.a;
+                    T::round_dt(g);
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) g[k] = g[k] * a.asym.S;
+                    T::round_dt(g);
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
                 }
-                q[e] = (int)as_u(p + 12582912.0f);
+            } else if (ac) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) f[e] = f[e] * sr.s;
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float g[T::EPD];
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] * sr.s;
+                    T::round_dt(g);
+#pragma unroll
+                    for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
+                }
             }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] = f[e] + magic;  // = magic + bin, exactly
+            if (mode == 1) {  // clamp the ROUNDED value (7.3 fits int4, 7.6 does not) -- integers below 2^24 compare exactly as floats
+                const float rlo = magic + a.cmin, rhi = magic + a.cmax;
+                uint32_t moved = 0;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float c = __builtin_amdgcn_fmed3f(f[e], rlo, rhi);
+                    moved += (c != f[e]) ? 1u : 0u;
+                    f[e] = c;
+                }
+                nbad += v < nvec ? moved : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) qu[e] = as_u(f[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
                 bool bad;
-                q[e] = sat_bin(b, a.cmin, a.cmax, bad);
+                qu[e] = MAGIC_U + (uint32_t)(sat_bin(b, a.cmin, a.cmax, bad) + ibias);
                 nbad += (bad && v < nvec) ? 1u : 0u;  // (a ballot + popcount per element made these rows ~10x slower than the others)
             }
         }
@@ -216,18 +263,25 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         if (cont == BINS_INT8) {
 #pragma unroll
             for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
-                const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * d + 1], (uint32_t)q[4 * d], 0x0c0c0400u);
-                const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * d + 3], (uint32_t)q[4 * d + 2], 0x04000c0cu);
+                const uint32_t lo = __builtin_amdgcn_perm(qu[4 * d + 1], qu[4 * d], 0x0c0c0400u);
+                const uint32_t hi = __builtin_amdgcn_perm(qu[4 * d + 3], qu[4 * d + 2], 0x04000c0cu);
                 pk[i][d] = lo | hi;
             }
         } else if (cont == BINS_INT4) {
-            uint32_t o = (uint32_t)q[0] & 0xFu;
+            // (hi << 4) + lo per pair: the low byte holds two offset nibbles, everything above it is the constant's junk;
+            // (t1 << 8) + t0 puts two such bytes into a clean low half
+            uint32_t h[EPV / 4];
 #pragma unroll
-            for (int e = 1; e < EPV; ++e) o |= ((uint32_t)q[e] & 0xFu) << (4 * e);
-            pk[i][0] = o;
+            for (int d = 0; d < EPV / 4; ++d) {
+                const uint32_t t0 = (qu[4 * d + 1] << 4) + qu[4 * d];
+                const uint32_t t1 = (qu[4 * d + 3] << 4) + qu[4 * d + 2];
+                h[d] = (t1 << 8) + t0;
+            }
+            if constexpr (EPV == 8) pk[i][0] = __builtin_amdgcn_perm(h[1], h[0], 0x05040100u) ^ flip;
+            else pk[i][0] = (h[0] ^ flip) & 0xFFFFu;
         } else {  // BINS_INT16
 #pragma unroll
-            for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm((uint32_t)q[2 * d + 1], (uint32_t)q[2 * d], 0x05040100u);
+            for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm(qu[2 * d + 1], qu[2 * d], 0x05040100u);
         }
     }
     // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16, else 8, 4 or 2.  Round 3

@@ -63,7 +63,7 @@ class _DeviceOf:
         self.prev = None
 
     def __enter__(self):
-        cur = torch.cuda.current_device()
+        cur = _cur_dev()
         if self.idx is not None and self.idx != cur:
             self.prev = cur
             torch.cuda.set_device(self.idx)
@@ -73,11 +73,19 @@ class _DeviceOf:
             torch.cuda.set_device(self.prev)
 
 
+# The raw current-stream handle / current device index straight from the C bindings (what Inductor's generated code uses):
+# 0.2 us per call instead of the 2-3 us `torch.cuda.current_stream().cuda_stream` spends building a Stream object.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+if _raw_stream is None:
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
+
+
 def _stream(x):
+    """the current stream of x's device, as the `hipStream_t` the C ABI takes"""
     idx = x.device.index
-    if idx is None or idx == torch.cuda.current_device():
-        return torch.cuda.current_stream().cuda_stream  # the argument-free form is several us cheaper
-    return torch.cuda.current_stream(idx).cuda_stream
+    return _raw_stream(_cur_dev() if idx is None else idx)
 
 
 _ws_bytes_memo = {}
@@ -170,13 +178,12 @@ def train_forward(kind, x, num_bits, layerwise, lo, hi):
     sp = side.data_ptr()
     fn = L.fq_sym_fwd_train if kind == "sym" else L.fq_asym_fwd_train
     dev = x.device.index
-    if dev is not None and dev != torch.cuda.current_device():
+    cur = _cur_dev()
+    if dev is not None and dev != cur:
         with torch.cuda.device(dev):
-            rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
-                    torch.cuda.current_stream(dev).cuda_stream)
+            rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes, _raw_stream(dev))
     else:
-        rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes,
-                torch.cuda.current_stream().cuda_stream)
+        rc = fn(x.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _semantics, lo, hi, sp, sp + rows * 8, mbytes, _raw_stream(cur))
     if rc:
         if rc == _lib.ERR_UNSUPPORTED:
             return None
@@ -195,13 +202,12 @@ def train_backward(grad_output, side, rows, cols, lo, hi, inplace=False):
     sp = side.data_ptr()
     dev = g.device.index
     L = _lib.lib()
-    if dev is not None and dev != torch.cuda.current_device():
+    cur = _cur_dev()
+    if dev is not None and dev != cur:
         with torch.cuda.device(dev):
-            rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code,
-                                   torch.cuda.current_stream(dev).cuda_stream)
+            rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code, _raw_stream(dev))
     else:
-        rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code,
-                               torch.cuda.current_stream().cuda_stream)
+        rc = L.fq_ste_bwd_mask(g.data_ptr(), gx.data_ptr(), rows, cols, lo, hi, sp, sp + rows * 8, side.numel() - rows * 8, code, _raw_stream(cur))
     if rc:
         _lib.check(rc, "ste_backward_mask")
     return gx

@@ -634,6 +634,28 @@ def _kv_hook(x, clip_val, num_bits):
     return None
 
 
+def conservative(flag=True):
+    """One switch for "the reference's structure, only faster": with it on, every reference call is exactly one kernel launch and one
+    autograd node, gradients are written out of place, and nothing is remembered between calls -- no operand pairing, no shared
+    activation fake-quant, no K/V pairing at the hooks, no weight cache, no sibling groups, no fused GEMM, no in-place weight
+    gradient.  Results are bit-identical either way (tests/test_tiny_llama.py::test_conservative_mode_is_bit_identical); the switch
+    exists to take the stateful host logic out of the picture when debugging a training run.  `conservative(False)` restores the
+    defaults (not the environment's settings).  Environment: LLMQAT_AMD_CONSERVATIVE=1."""
+    pair_operands(not flag)
+    share_activation_quant(not flag)
+    pair_kv_hooks(not flag)
+    inplace_weight_grad(not flag)
+    if flag:
+        enable_weight_quant_cache(False)
+        group_siblings(False)
+        fuse_qlinear(False)
+        fuse_low_bit_mean(False)
+
+
+if os.environ.get("LLMQAT_AMD_CONSERVATIVE", "0") == "1":
+    conservative(True)
+
+
 class _ReuseQuantizedWeight(torch.autograd.Function):
     """Autograd node over an already computed (value, row bounds, STE mask) triple of a weight:
     forward launches nothing, backward is the ordinary STE backward."""

@@ -214,3 +214,42 @@ def test_training_steps_with_sibling_grouping_match_eager_chain(reentrant, group
         assert torch.equal(a, b), (s, a.item(), b.item())
     for a, b, (n, _) in zip(p, p_ref, ours.named_parameters()):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("autocast", [False, True])
+def test_conservative_mode_is_bit_identical(autocast):
+    """`llm_qat_amd.conservative(True)` (LLMQAT_AMD_CONSERVATIVE=1): one launch and one autograd node per reference call, nothing
+    remembered between calls, every gradient out of place.  Same loss, logits and gradients, bit for bit, as the default settings
+    and as the eager chain; and it really launches per call (no pair / multi launch, 2 x 7 forward launches per layer + 2 KV hooks)."""
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+    llm_qat_amd.set_semantics("device_eager")
+    counts = {"pair": 0, "multi": 0}
+    orig_pair, orig_multi = llm_qat_amd.ops.pair_forward, llm_qat_amd.ops.multi_forward
+    llm_qat_amd.ops.pair_forward = lambda *a, **k: (counts.__setitem__("pair", counts["pair"] + 1), orig_pair(*a, **k))[1]
+    llm_qat_amd.ops.multi_forward = lambda *a, **k: (counts.__setitem__("multi", counts["multi"] + 1), orig_multi(*a, **k))[1]
+    try:
+        outs = []
+        for which in ("eager", "default", "conservative"):
+            quant = TL.EagerQuant() if which == "eager" else UQ
+            llm_qat_amd.conservative(which == "conservative")
+            m = TL.load_deterministic(TL.TinyLlama(quant, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+            before = dict(counts)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                loss, logits = m(ids, labels=ids)
+            loss.backward()
+            outs.append((loss.detach(), logits.detach(), [p.grad.clone() for p in m.parameters()], [n for n, _ in m.named_parameters()]))
+            if which == "default":
+                assert counts["pair"] > before["pair"], "the default settings pair operands"
+            if which == "conservative":
+                assert counts == before, "conservative mode must not pair or group anything"
+        for other in outs[1:]:
+            assert torch.equal(outs[0][0], other[0]) and torch.equal(outs[0][1], other[1])
+            for a, b, n in zip(outs[0][2], other[2], outs[0][3]):
+                assert torch.equal(a, b), n
+    finally:
+        llm_qat_amd.ops.pair_forward, llm_qat_amd.ops.multi_forward = orig_pair, orig_multi
+        llm_qat_amd.conservative(False)
+        llm_qat_amd.set_semantics("cpu_eager")

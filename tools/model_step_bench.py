@@ -93,7 +93,8 @@ def main():
             for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
                                          ("llm_qat_amd", UQ, False), ("llm_qat_amd + sibling groups (opt-in)", UQ, False),
                                          ("llm_qat_amd + K/V in one launch", UQ, False),
-                                         ("llm_qat_amd + weight cache", UQ, True)):
+                                         ("llm_qat_amd + weight cache", UQ, True),
+                                         ("llm_qat_amd conservative (one launch + one node per reference call)", UQ, False)):
                 if args.only and label != args.only:
                     continue
                 TL.KV_ONE_LAUNCH = "K/V" in label
@@ -101,6 +102,7 @@ def main():
                     model = build(quant, args.layers, 32, 32, 32)
                 else:
                     model = build(quant, args.layers, wb, ab, kvb)
+                llm_qat_amd.conservative("conservative" in label)
                 llm_qat_amd.enable_weight_quant_cache(wcache)
                 llm_qat_amd.group_siblings("sibling groups" in label and "groups off" not in label)
                 torch.cuda.reset_peak_memory_stats()
@@ -112,6 +114,7 @@ def main():
                             p.mul_(1.0)
                 ms = timed(lambda: step(model, ids, ckpt), args.iters, touch_weights)
                 llm_qat_amd.group_siblings(False)   # the default
+                llm_qat_amd.conservative(False)
                 peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
                 llm_qat_amd.enable_weight_quant_cache(False)
                 rows.append(dict(cfg=f"W{wb}A{ab}KV{kvb}", checkpointing=ckpt, autocast=AUTOCAST, impl=label, ms_per_step=round(ms, 2), layers=args.layers, dims=MODEL,

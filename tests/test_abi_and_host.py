@@ -234,3 +234,26 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     assert L.fq_sym_fwd_multi(2, t, 64, 1, 0, 0, -2.0, 2.0, None) in (-2, -3, -4)                         # zeroed descriptors are rejected
     assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, 0, None) == -2
     assert b"bits" in L.fq_last_error() or b"w_bits" in L.fq_last_error()
+
+
+def test_conservative_switch_turns_every_stateful_host_optimisation_off_and_back_on():
+    """llm_qat_amd.conservative(True): one launch + one autograd node per reference call, nothing remembered between calls
+    (the GPU tier checks that results stay bit-identical: tests/test_tiny_llama.py::test_conservative_mode_is_bit_identical)"""
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    names = ("_PAIR", "_SHARE_ACT", "_PAIR_KV", "_INPLACE_WGRAD", "_WEIGHT_CACHE", "_GROUP", "_FUSED_QLINEAR", "_W12_FUSED")
+    before = {n: getattr(UQ, n) for n in names}
+    try:
+        llm_qat_amd.enable_weight_quant_cache(True)
+        llm_qat_amd.group_siblings(True)
+        llm_qat_amd.conservative(True)
+        assert not any(getattr(UQ, n) for n in names), {n: getattr(UQ, n) for n in names}
+        llm_qat_amd.conservative(False)
+        assert UQ._PAIR and UQ._SHARE_ACT and UQ._PAIR_KV and UQ._INPLACE_WGRAD      # the defaults
+        assert not (UQ._WEIGHT_CACHE or UQ._GROUP or UQ._FUSED_QLINEAR or UQ._W12_FUSED)   # opt-ins stay off
+    finally:
+        UQ._PAIR, UQ._SHARE_ACT, UQ._PAIR_KV, UQ._INPLACE_WGRAD = before["_PAIR"], before["_SHARE_ACT"], before["_PAIR_KV"], before["_INPLACE_WGRAD"]
+        llm_qat_amd.enable_weight_quant_cache(before["_WEIGHT_CACHE"])
+        llm_qat_amd.group_siblings(before["_GROUP"])
+        llm_qat_amd.fuse_qlinear(before["_FUSED_QLINEAR"])
+        llm_qat_amd.fuse_low_bit_mean(before["_W12_FUSED"])

@@ -11,6 +11,8 @@
 // in bf16 an 8-bit row can hold the bin +128 (and a 16-bit row bins beyond 32767); the count makes that explicit instead of
 // silently changing a value.  A row whose top bin fits skips the counting entirely (the bin is monotone in |x| / in x).
 #pragma once
+#include <type_traits>
+
 #include "fq_kernels.h"
 
 namespace fq {
@@ -59,6 +61,173 @@ template <int DT> __device__ __forceinline__ float asym_bin(float x, const AsymR
 }
 template <int DT> __device__ __forceinline__ float sym_bin(float x, const SymRow& r, bool autocast) {
     return autocast ? __builtin_rintf(x * r.s) : __builtin_rintf(Ty<DT>::rb(x * r.s));
+}
+
+// The elementwise half of row_export_kernel: STE mask (scale pre-pass only), bins, packing, stores; returns this lane's count of bins
+// that did not fit.  CONT / AC / MASK >= 0 fix the container, the autocast arithmetic and "no mask" at COMPILE time, -1 reads them
+// from the arguments.  They are the same for every block of a launch, but as run-time values they cost the 512 x 3 kernel 7 % on the
+// metric tensor (a dozen scalar branches per vector slot: profiles/r03_ab_export_constexpr_flags.txt), so the kernel calls the
+// specialised bodies for the deployment formats -- Sym, no autocast, int4 / int8 -- and the general one for everything else.
+template <int DT, int TPR, int VPT, bool ASYM, int CONT, int AC, int MASK>
+__device__ __forceinline__ uint32_t export_row_body(const ExportArgs& a, const uint4 (&r)[VPT], int64_t row, int t, int nvec, const SymRow& sr,
+                                                    const AsymRow& ar, float ub, float lb, float top, bool& count) {
+    using T = Ty<DT>;
+    constexpr int EPV = 16 / T::ESIZE;
+    const bool ac = AC < 0 ? a.autocast != 0 : AC != 0;
+    const bool want_mask = MASK == 0 ? false : (a.mask && !((ub < a.hi) && (lb > a.lo)));  // block-uniform
+    const bool sym_clip = a.lo == -a.hi;
+    const uint32_t clipk = (ub != ub) ? 0u : a.clipk;
+    uint8_t* mrow = (uint8_t*)(a.mask + row * a.mask_row_words);
+    const int cont = CONT < 0 ? a.container : CONT;
+    // Sym: only the positive side can exceed a signed container whose top bin is cmax + 1 (-128 fits int8, +128 does not)
+    count = cont != BINS_NONE && !(top <= a.cmax);  // block-uniform; true for a NaN row
+    if (cont == BINS_NONE && !want_mask) return 0u;  // the scale pre-pass: nothing elementwise to do
+    // How a row's bins become integers (block-uniform):
+    //   0  the row's top bin fits the container, so every bin does and none is NaN: the integer comes out of ONE add --
+    //      p + 1.5 * 2^23 rounds p to an integer (half to even, like torch.round) and leaves its two's complement in the low
+    //      mantissa bits (|p| < 2^22 holds for every container);
+    //   1  the top bin is finite but does not fit (a bf16 8-bit row whose top bin is +128, 16-bit bins into int8, ...): p is an
+    //      ordinary number everywhere in the row, so v_med3_f32 clamps the sum behind the same add and a compare counts what moved;
+    //   2  NaN / Inf / huge rows: saturate and count element by element (sat_bin).
+    const int row_mode = !count ? 0 : (top < 4194304.0f ? 1 : 2);
+    // int4: nibbles are built in offset binary (bin - cmin in 0..15, so neighbours cannot borrow from each other) with shift-adds
+    // on the raw sums and flipped to two's complement by one XOR per stored dword.  The offset rides in the rounding constant (an
+    // even integer: ties still go to even).
+    const int ibias = (cont == BINS_INT4 && !ASYM) ? 8 : 0;  // = -cmin: Sym containers are signed, Asym ones start at 0 (export_entry)
+    const float magic = 12582912.0f + (float)ibias;
+    const uint32_t flip = ibias ? 0x88888888u : 0u;
+    constexpr uint32_t MAGIC_U = 0x4B400000u;  // bits of 1.5 * 2^23
+    char* brow = (char*)a.bins + row * a.row_bytes;
+    uint32_t nbad = 0;  // per lane; summed over the wave after the loop
+    uint32_t pk[VPT][4] = {};  // this lane's packed bins per slot (EPV * container bits / 32 dwords used)
+    // The slot loop, once per way of a row (the specialised bodies) or with the way as a run-time value (the general body): the
+    // way is block-uniform, so the specialised bodies branch on it once instead of two or three times per slot.
+    auto slots = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const int mode = MODE < 0 ? row_mode : MODE;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * TPR;
+            const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            float f[EPV];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float fd[T::EPD];
+                T::unpack(w[d], fd);
+#pragma unroll
+                for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
+            }
+            if (want_mask) ste_mask_record<DT>(mrow, v, v < nvec, r[i], f, a.lo, a.hi, sym_clip, clipk);
+            if (cont == BINS_NONE) continue;
+            uint32_t qu[EPV];  // MAGIC_U + ibias + bin
+            if (mode < 2) {
+                // p = what torch.round() sees, dword by dword so that the multiplies, roundings and the final add pair up
+                // (v_pk_mul_f32, ONE v_cvt_pk_bf16_f32 per pair, v_pk_add_f32); the autocast switch is taken once per slot
+                if constexpr (ASYM) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float g[T::EPD];
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] - ar.mn;
+                        T::round_dt(g);
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) g[k] = ar.mk ? div_exact(g[k], ar.a, ar.ra) : g[k] / ar.a;
+                        T::round_dt(g);
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) g[k] = g[k] * a.asym.S;
+                        T::round_dt(g);
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
+                    }
+                } else if (ac) {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) f[e] = f[e] * sr.s;
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float g[T::EPD];
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] * sr.s;
+                        T::round_dt(g);
+#pragma unroll
+                        for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) f[e] = f[e] + magic;  // = magic + bin, exactly
+                if (mode == 1) {  // clamp the ROUNDED value (7.3 fits int4, 7.6 does not) -- integers below 2^24 compare exactly as floats
+                    const float rlo = magic + a.cmin, rhi = magic + a.cmax;
+                    uint32_t moved = 0;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const float c = __builtin_amdgcn_fmed3f(f[e], rlo, rhi);
+                        moved += (c != f[e]) ? 1u : 0u;
+                        f[e] = c;
+                    }
+                    nbad += v < nvec ? moved : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) qu[e] = as_u(f[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
+                    bool bad;
+                    qu[e] = MAGIC_U + (uint32_t)(sat_bin(b, a.cmin, a.cmax, bad) + ibias);
+                    nbad += (bad && v < nvec) ? 1u : 0u;  // (a ballot + popcount per element made these rows ~10x slower than the others)
+                }
+            }
+            // pack this slot's bins; the stores follow the loop
+            if (cont == BINS_INT8) {
+#pragma unroll
+                for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
+                    const uint32_t lo = __builtin_amdgcn_perm(qu[4 * d + 1], qu[4 * d], 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm(qu[4 * d + 3], qu[4 * d + 2], 0x04000c0cu);
+                    pk[i][d] = lo | hi;
+                }
+            } else if (cont == BINS_INT4) {
+                // (hi << 4) + lo per pair: the low byte holds two offset nibbles, everything above it is the constant's junk;
+                // (t1 << 8) + t0 puts two such bytes into a clean low half
+                uint32_t h[EPV / 4];
+#pragma unroll
+                for (int d = 0; d < EPV / 4; ++d) {
+                    const uint32_t t0 = (qu[4 * d + 1] << 4) + qu[4 * d];
+                    const uint32_t t1 = (qu[4 * d + 3] << 4) + qu[4 * d + 2];
+                    h[d] = (t1 << 8) + t0;
+                }
+                if constexpr (EPV == 8) pk[i][0] = __builtin_amdgcn_perm(h[1], h[0], 0x05040100u) ^ flip;
+                else pk[i][0] = (h[0] ^ flip) & 0xFFFFu;
+            } else {  // BINS_INT16
+#pragma unroll
+                for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm(qu[2 * d + 1], qu[2 * d], 0x05040100u);
+            }
+        }
+    };
+    if constexpr (CONT >= 0) {
+        if (row_mode == 0) slots(std::integral_constant<int, 0>{});
+        else if (row_mode == 1) slots(std::integral_constant<int, 1>{});
+        else slots(std::integral_constant<int, 2>{});
+    } else {
+        slots(std::integral_constant<int, -1>{});
+    }
+    // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16, else 8, 4 or 2.  Round 3
+    // built the alternative -- lane pairs / quads trade packed dwords over two / four slots so that every storing lane writes 16
+    // bytes -- and measured it against these plain stores on one box (profiles/r03_ab_export_store_width.txt): int4 22.22 vs 22.23 us,
+    // int8 25.1-25.6 vs 25.7-27.4 us.  The store width is not what keeps these kernels above their streaming ceilings, so the simple
+    // form stays.
+    if (cont != BINS_NONE) {
+        const int vb = cont == BINS_INT4 ? EPV / 2 : cont == BINS_INT8 ? EPV : 2 * EPV;  // bytes per vector
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = t + i * TPR;
+            if (v >= nvec) continue;
+            if (vb == 16) st16<true>((uint4*)brow + v, make_uint4(pk[i][0], pk[i][1], pk[i][2], pk[i][3]));
+            else if (vb == 8) st8<true>((uint2*)brow + v, make_uint2(pk[i][0], pk[i][1]));
+            else if (vb == 4) __builtin_nontemporal_store(pk[i][0], (uint32_t*)brow + v);
+            else __builtin_nontemporal_store((uint16_t)pk[i][0], (uint16_t*)brow + v);
+        }
+    }
+    return nbad;
 }
 
 template <int DT, int TPR, int VPT, bool ASYM, bool NTL>
@@ -157,149 +326,15 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
         a.bounds[2 * row + 1] = lb;
     }
 
-    const bool want_mask = a.mask && !((ub < a.hi) && (lb > a.lo));  // block-uniform
-    const bool sym_clip = a.lo == -a.hi;
-    const uint32_t clipk = (ub != ub) ? 0u : a.clipk;
-    uint8_t* mrow = (uint8_t*)(a.mask + row * a.mask_row_words);
-    const int cont = a.container;  // (as a compile-time constant -- what templating the kernel on it would give -- it measured 2-3 % faster:
-    //                                profiles/r03_ab_export_container_constexpr.txt; not worth four times the instantiations)
-    // Sym: only the positive side can exceed a signed container whose top bin is cmax + 1 (-128 fits int8, +128 does not)
-    const bool count = cont != BINS_NONE && !(top <= a.cmax);  // block-uniform; true for a NaN row
-    if (cont == BINS_NONE && !want_mask) {
-        if (t == 0 && a.overflow) a.overflow[row] = 0;
-        return;  // the scale pre-pass: nothing elementwise to do
-    }
-    // How a row's bins become integers (block-uniform):
-    //   0  the row's top bin fits the container, so every bin does and none is NaN: the integer comes out of ONE add --
-    //      p + 1.5 * 2^23 rounds p to an integer (half to even, like torch.round) and leaves its two's complement in the low
-    //      mantissa bits (|p| < 2^22 holds for every container);
-    //   1  the top bin is finite but does not fit (a bf16 8-bit row whose top bin is +128, 16-bit bins into int8, ...): p is an
-    //      ordinary number everywhere in the row, so v_med3_f32 clamps the sum behind the same add and a compare counts what moved;
-    //   2  NaN / Inf / huge rows: saturate and count element by element (sat_bin).
-    const int mode = !count ? 0 : (top < 4194304.0f ? 1 : 2);
-    // int4: nibbles are built in offset binary (bin - cmin in 0..15, so neighbours cannot borrow from each other) with shift-adds
-    // on the raw sums and flipped to two's complement by one XOR per stored dword.  The offset rides in the rounding constant (an
-    // even integer: ties still go to even).
-    const int ibias = cont == BINS_INT4 ? -(int)a.cmin : 0;
-    const float magic = 12582912.0f + (float)ibias;
-    const uint32_t flip = ibias ? 0x88888888u : 0u;
-    constexpr uint32_t MAGIC_U = 0x4B400000u;  // bits of 1.5 * 2^23
-    char* brow = (char*)a.bins + row * a.row_bytes;
-    uint32_t nbad = 0;  // per lane; summed over the wave after the loop
-    uint32_t pk[VPT][4] = {};  // this lane's packed bins per slot (EPV * container bits / 32 dwords used)
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int v = t + i * TPR;
-        const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        float f[EPV];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            float fd[T::EPD];
-            T::unpack(w[d], fd);
-#pragma unroll
-            for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = fd[k];
-        }
-        if (want_mask) ste_mask_record<DT>(mrow, v, v < nvec, r[i], f, a.lo, a.hi, sym_clip, clipk);
-        if (cont == BINS_NONE) continue;
-        uint32_t qu[EPV];  // MAGIC_U + ibias + bin
-        if (mode < 2) {
-            // p = what torch.round() sees, dword by dword so that the multiplies, roundings and the final add pair up
-            // (v_pk_mul_f32, ONE v_cvt_pk_bf16_f32 per pair, v_pk_add_f32); the autocast switch is taken once per slot
-            if constexpr (ASYM) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    float g[T::EPD];
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] - ar.mn;
-                    T::round_dt(g);
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) g[k] = ar.mk ? div_exact(g[k], ar.a, ar.ra) : g[k] / ar.a;
-                    T::round_dt(g);
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) g[k] = g[k] * a.asym.S;
-                    T::round_dt(g);
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
-                }
-            } else if (ac) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) f[e] = f[e] * sr.s;
-            } else {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    float g[T::EPD];
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) g[k] = f[d * T::EPD + k] * sr.s;
-                    T::round_dt(g);
-#pragma unroll
-                    for (int k = 0; k < T::EPD; ++k) f[d * T::EPD + k] = g[k];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) f[e] = f[e] + magic;  // = magic + bin, exactly
-            if (mode == 1) {  // clamp the ROUNDED value (7.3 fits int4, 7.6 does not) -- integers below 2^24 compare exactly as floats
-                const float rlo = magic + a.cmin, rhi = magic + a.cmax;
-                uint32_t moved = 0;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    const float c = __builtin_amdgcn_fmed3f(f[e], rlo, rhi);
-                    moved += (c != f[e]) ? 1u : 0u;
-                    f[e] = c;
-                }
-                nbad += v < nvec ? moved : 0u;
-            }
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) qu[e] = as_u(f[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float b = ASYM ? asym_bin<DT>(f[e], ar, a.asym) : sym_bin<DT>(f[e], sr, ac);
-                bool bad;
-                qu[e] = MAGIC_U + (uint32_t)(sat_bin(b, a.cmin, a.cmax, bad) + ibias);
-                nbad += (bad && v < nvec) ? 1u : 0u;  // (a ballot + popcount per element made these rows ~10x slower than the others)
-            }
-        }
-        // pack this slot's bins; the stores follow the loop
-        if (cont == BINS_INT8) {
-#pragma unroll
-            for (int d = 0; d < EPV / 4; ++d) {  // v_perm_b32: low bytes of four dwords into one
-                const uint32_t lo = __builtin_amdgcn_perm(qu[4 * d + 1], qu[4 * d], 0x0c0c0400u);
-                const uint32_t hi = __builtin_amdgcn_perm(qu[4 * d + 3], qu[4 * d + 2], 0x04000c0cu);
-                pk[i][d] = lo | hi;
-            }
-        } else if (cont == BINS_INT4) {
-            // (hi << 4) + lo per pair: the low byte holds two offset nibbles, everything above it is the constant's junk;
-            // (t1 << 8) + t0 puts two such bytes into a clean low half
-            uint32_t h[EPV / 4];
-#pragma unroll
-            for (int d = 0; d < EPV / 4; ++d) {
-                const uint32_t t0 = (qu[4 * d + 1] << 4) + qu[4 * d];
-                const uint32_t t1 = (qu[4 * d + 3] << 4) + qu[4 * d + 2];
-                h[d] = (t1 << 8) + t0;
-            }
-            if constexpr (EPV == 8) pk[i][0] = __builtin_amdgcn_perm(h[1], h[0], 0x05040100u) ^ flip;
-            else pk[i][0] = (h[0] ^ flip) & 0xFFFFu;
-        } else {  // BINS_INT16
-#pragma unroll
-            for (int d = 0; d < EPV / 2; ++d) pk[i][d] = __builtin_amdgcn_perm(qu[2 * d + 1], qu[2 * d], 0x05040100u);
-        }
-    }
-    // ---- stores.  A lane's packed vector is EPV * bits / 8 bytes: 16 only for 16-bit elements into int16, else 8, 4 or 2.  Round 3
-    // built the alternative -- lane pairs / quads trade packed dwords over two / four slots so that every storing lane writes 16
-    // bytes -- and measured it against these plain stores on one box (profiles/r03_ab_export_store_width.txt): int4 22.22 vs 22.23 us,
-    // int8 25.1-25.6 vs 25.7-27.4 us.  The store width is not what keeps these kernels above their streaming ceilings, so the simple
-    // form stays.
-    if (cont != BINS_NONE) {
-        const int vb = cont == BINS_INT4 ? EPV / 2 : cont == BINS_INT8 ? EPV : 2 * EPV;  // bytes per vector
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = t + i * TPR;
-            if (v >= nvec) continue;
-            if (vb == 16) st16<true>((uint4*)brow + v, make_uint4(pk[i][0], pk[i][1], pk[i][2], pk[i][3]));
-            else if (vb == 8) st8<true>((uint2*)brow + v, make_uint2(pk[i][0], pk[i][1]));
-            else if (vb == 4) __builtin_nontemporal_store(pk[i][0], (uint32_t*)brow + v);
-            else __builtin_nontemporal_store((uint16_t)pk[i][0], (uint16_t*)brow + v);
-        }
+    uint32_t nbad;  // per lane; summed over the wave below
+    bool count;     // block-uniform: the row's top bin does not fit the container
+    if constexpr (!ASYM) {
+        const bool plain = !a.mask && !ac;  // the same for every block of the launch
+        if (plain && a.container == BINS_INT4) nbad = export_row_body<DT, TPR, VPT, false, BINS_INT4, 0, 0>(a, r, row, t, nvec, sr, ar, ub, lb, top, count);
+        else if (plain && a.container == BINS_INT8) nbad = export_row_body<DT, TPR, VPT, false, BINS_INT8, 0, 0>(a, r, row, t, nvec, sr, ar, ub, lb, top, count);
+        else nbad = export_row_body<DT, TPR, VPT, false, -1, -1, -1>(a, r, row, t, nvec, sr, ar, ub, lb, top, count);
+    } else {
+        nbad = export_row_body<DT, TPR, VPT, true, -1, 0, -1>(a, r, row, t, nvec, sr, ar, ub, lb, top, count);
     }
     if (a.overflow) {
         if (!count) {

@@ -75,6 +75,54 @@ __global__ __launch_bounds__(256) void shrink_kernel(const uint4* __restrict__ i
     }
 }
 
+// The export kernels' STRUCTURE without their arithmetic: one row per block, the row loaded once into registers (VPT x 16 B per
+// thread, NT), a block-wide max through LDS (one barrier -- the stores depend on every load of the row), then 16 / R bytes per
+// vector slot written with NT stores (R = 2: 8 B as int8 bins, R = 4: 4 B as int4 bins).  Against shrink_kernel (same bytes, no row
+// structure) this isolates what the load -> reduce -> store dependency of a row-resident block costs for these byte ratios.
+template <int R, int TPR, int VPT>
+__global__ __launch_bounds__(TPR) void rowshrink_kernel(const uint4* __restrict__ in, uint32_t* __restrict__ out, int nvec_row) {
+    __shared__ uint32_t red[TPR / 64];
+    const int t = threadIdx.x;
+    const uint4* xr = in + (int64_t)blockIdx.x * nvec_row;
+    uint4 r[VPT];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        int v = t + i * TPR;
+        v = v < nvec_row ? v : nvec_row - 1;
+        r[i] = ld_nt(&xr[v]);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const uint32_t m = (r[i].x | r[i].y | r[i].z | r[i].w) & 0x7FFF7FFFu;
+        acc = acc > m ? acc : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)acc, o, 64);
+        acc = acc > other ? acc : other;
+    }
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    uint32_t m = red[0];
+#pragma unroll
+    for (int w = 1; w < TPR / 64; ++w) m = m > red[w] ? m : red[w];
+    constexpr int DW = 4 / R;  // dwords stored per slot
+    uint32_t* orow = out + (int64_t)blockIdx.x * nvec_row * DW;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = t + i * TPR;
+        if (v >= nvec_row) continue;
+        if constexpr (R == 4) {
+            __builtin_nontemporal_store((r[i].x ^ r[i].y ^ r[i].z ^ r[i].w) + m, orow + v);
+        } else {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 w = {(r[i].x ^ r[i].y) + m, (r[i].z ^ r[i].w) + m};
+            __builtin_nontemporal_store(w, (u32x2*)orow + v);
+        }
+    }
+}
+
 // grid-stride copy: fixed grid, each block walks tiles
 template <int UNR, bool NT>
 __global__ __launch_bounds__(256) void copy_gs_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t nvec) {
@@ -388,6 +436,17 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (argc > 3 && std::string(argv[3]) == "ceilings") {
+        if (cols % 8 == 0 && cols / 8 <= 512 * 3 && cols / 8 > 512 * 2) {   // the export kernels' launch shape for 11008-column rows
+            report("rowshrink<read 2 : write 1, 512 x 3> (export structure, no arithmetic)", 1.5 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((rowshrink_kernel<2, 512, 3>), dim3((unsigned)rows), dim3(512), 0, 0, (const uint4*)b.x[i % NS], (uint32_t*)b.y[i % NS], (int)(cols / 8));
+                   }, IT));
+            report("rowshrink<read 4 : write 1, 512 x 3> (export structure, no arithmetic)", 1.25 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((rowshrink_kernel<4, 512, 3>), dim3((unsigned)rows), dim3(512), 0, 0, (const uint4*)b.x[i % NS], (uint32_t*)b.y[i % NS], (int)(cols / 8));
+                   }, IT));
+            report("rowshrink<read 4 : write 1, 256 x 6> (export structure, no arithmetic)", 1.25 * bytes, time_it([&](int i) {
+                       hipLaunchKernelGGL((rowshrink_kernel<4, 256, 6>), dim3((unsigned)rows), dim3(256), 0, 0, (const uint4*)b.x[i % NS], (uint32_t*)b.y[i % NS], (int)(cols / 8));
+                   }, IT));
+        }
         report("read-only<UNR=4>", 1.0 * bytes, time_it([&](int i) {
                    hipLaunchKernelGGL((read_kernel<4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, 0, (const uint4*)b.x[i % NS], sink, nvec);
                }, IT));

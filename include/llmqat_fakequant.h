@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define FQ_ABI_VERSION 3 /* 2: + multi-tensor launches, export, row scales, fq_qlinear_fwd, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap */
+#define FQ_ABI_VERSION 4 /* 2: + multi-tensor launches, export, row scales, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap;
+                            4: fq_sym_fwd_autocast takes `sem` (and the autocast modes of pair / multi / export / row_scales honour it),
+                               FQ_ERR_PENDING, fq_qlinear_fwd (an experiment with test hooks in its signature) left the library */
 
 /* element types */
 #define FQ_DTYPE_F32 0
@@ -43,7 +45,11 @@ extern "C" {
  * (+ _debug; no row bounds), fq_ste_bwd and fq_w12_fwd; every other entry point answers FQ_ERR_DTYPE for it. */
 #define FQ_DTYPE_F64 3
 
-/* scalar semantics (only differ for bf16/fp16 rows with |max| < ~4e-5, and Asym fp32 `.div(S)`) */
+/* scalar semantics: how a Python scalar ADDED to a 16-bit tensor is treated (`max + 1e-6`, `alpha + 1e-8`), and Asym's `.div(S)`.
+ * The two differ only where 1e-6 is within a rounding step of the row's |max|: bf16 rows with |max| below ~3e-4, fp16 rows with
+ * |max| in [2^-13, 2^-12) (1e-6 lands on a tie there); and for fp32 Asym.  Under the autocast arithmetic (fq_sym_fwd_autocast and
+ * the autocast modes of pair / multi / export / row_scales) `sem` governs `max + 1e-6` alone -- everything behind it is fp32 -- and
+ * a real torch.autocast("cuda") run is FQ_SEM_DEVICE_EAGER by definition. */
 #define FQ_SEM_CPU_EAGER 0    /* canonical: what ATen's CPU kernels do; pinned by tests/golden */
 #define FQ_SEM_DEVICE_EAGER 1 /* what ATen's GPU kernels do (fp32 "opmath" scalars, div-by-scalar = mul by 1/S) */
 
@@ -57,6 +63,8 @@ extern "C" {
 #define FQ_ERR_LAUNCH (-6)
 #define FQ_ERR_ARG (-7)
 #define FQ_ERR_UNSUPPORTED (-8) /* shape/alignment not served by this entry point: use the general one */
+#define FQ_ERR_PENDING (-9)     /* a HIP error raised by an EARLIER launch / another library was pending on this thread: nothing was
+                                   launched, the error is left in place (hipGetLastError() still returns it to its owner) */
 
 int fq_version(void);               /* == FQ_ABI_VERSION */
 const char* fq_build_info(void);    /* e.g. "llmqat_fakequant abi 1, gfx950, hip 7.2" */
@@ -162,6 +170,8 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
  * returns an fp32 tensor.  (fp32 inputs are unaffected by autocast: use fq_sym_fwd.  AsymQuantizer and the 1-/2-bit
  * branches contain no autocast-listed op: use fq_asym_fwd / fq_w12_fwd.)
  *   dtype     FQ_DTYPE_BF16 or FQ_DTYPE_F16 (the input)
+ *   sem       FQ_SEM_DEVICE_EAGER is what the device computes under torch.autocast("cuda"); FQ_SEM_CPU_EAGER rounds the 1e-6 of
+ *             `max + 1e-6` to the tensor dtype first (the reference's CPU behaviour: tests/golden/autocast.npz holds both)
  *   wide_out  1: y is fp32 [rows, cols], exactly what the reference returns (KV hooks, direct callers)
  *             0: y has the input dtype = that fp32 result rounded once to it -- bit-identical to what F.linear's own
  *                autocast cast makes of it next, so QuantizeLinear can skip the fp32 round trip (2 instead of 4+4+2 B/elem)
@@ -174,7 +184,7 @@ int fq_ste_bwd_mask(const void* g, void* gx, int64_t rows, int64_t cols, float l
  *   workspace  fq_rowwise_workspace_bytes(rows, cols, dtype) bytes (only rows longer than 32768 elements use it)
  * Returns FQ_ERR_UNSUPPORTED when a mask is requested for a shape fq_ste_mask_bytes rejects or for misaligned rows.
  */
-int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
+int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, int wide_out, float lo, float hi,
                         float* row_bounds_out, void* mask_out, size_t mask_bytes, void* workspace, size_t workspace_bytes,
                         void* stream);
 
@@ -299,32 +309,12 @@ int fq_asym_export(const void* x, void* bins_out, float* scales_out, int32_t* ov
  * The reduction half of SymQuantizer.forward alone (models/utils_quant.py:53-59,:71): per-row  s = reciprocal(max|x| +
  * 1e-6) * qmax  and  t2 = s + 1e-6  -> scales_out[rows][2] = {s, t2}; x is read once (2 B/elem bf16), nothing
  * elementwise is written.  Optionally also records what a training-mode forward records for the STE backward
- * (row_bounds_out + mask_out, exactly as fq_sym_fwd_train; lo / hi = the clip).  This is the pre-pass of the fused
- * QuantizeLinear forward (fq_qlinear_fwd): with {s, t2} known per row, `round(x * s) / t2` is a pure elementwise map that
- * the GEMM can apply to its operand tiles as it loads them.
+ * (row_bounds_out + mask_out, exactly as fq_sym_fwd_train; lo / hi = the clip).  With {s, t2} known per row, `round(x * s) / t2`
+ * is a pure elementwise map: what a consumer that applies the fake-quant itself needs (an export's dequantisation check; the
+ * quantize-on-load GEMM experiment under tools/qlinear/).
  */
 int fq_sym_row_scales(const void* x, float* scales_out, int64_t rows, int64_t cols, int bits, int dtype, int sem, int autocast, float lo,
                       float hi, float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
-
-/*
- * QuantizeLinear.forward without a backward (eval, or the first pass of a reentrant-checkpointed layer,
- * models/modeling_llama_quant.py:732-747) with the fake-quant fused into the GEMM's operand loads:
- *     out[tokens, out] = fq(x)[tokens, in] . fq(W)[out, in]^T        (models/utils_quant.py:195-201, :244-250)
- * x_scales / w_scales are the per-row {s, t2} of fq_sym_row_scales (float[rows][2]); an operand whose scales pointer is
- * NULL is multiplied AS IS (e.g. an activation a sibling projection has already fake-quantized).  The staged operand
- * values are bit-identical to fq_sym_fwd's (autocast = 0) or to fq_sym_fwd_autocast's bf16-rounded result (autocast = 1);
- * the product accumulates in fp32 on the matrix cores (v_mfma_f32_32x32x16_bf16) and is rounded once to bf16, so it
- * differs from F.linear only by the order of the fp32 accumulation.
- *   dtype      FQ_DTYPE_BF16 (operands and result)
- *   dump_x / dump_w   optional [tokens, in] / [out, in] bf16 buffers that receive the operand tiles exactly as staged
- *                     for the MFMAs (test hook: compare with fq_sym_fwd)
- *   ablation   0; 1 / 2 are timing builds of the cost model (1: staging pipeline without MFMAs, 2: LDS reads + MFMAs
- *              without staging) whose result is garbage
- * FQ_ERR_UNSUPPORTED unless in_features % 64 == 0, out_features % 4 == 0, x / w 16-byte and out 8-byte aligned.
- */
-int fq_qlinear_fwd(const void* x, const float* x_scales, const void* w, const float* w_scales, void* out, int64_t tokens,
-                   int64_t in_features, int64_t out_features, int dtype, int autocast, void* dump_x, void* dump_w, int ablation,
-                   void* stream);
 
 #ifdef __cplusplus
 }

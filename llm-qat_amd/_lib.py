@@ -8,7 +8,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libllmqat_fakequant.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
 SEM_CPU_EAGER, SEM_DEVICE_EAGER = 0, 1
@@ -20,7 +20,7 @@ EXPORTS = (
     "fq_ste_bwd", "fq_ste_bwd_rows",
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
     "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
-    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_qlinear_fwd", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi", "fq_w12_fwd_rows",
+    "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi", "fq_w12_fwd_rows",
 )
 MAX_TENSORS = 4  # tensors per multi-tensor launch
 
@@ -35,6 +35,7 @@ class BwdTensor(ctypes.Structure):  # fq_bwd_tensor
 
 BINS_NONE, BINS_INT4, BINS_INT8, BINS_INT16 = 0, 1, 2, 3
 ERR_UNSUPPORTED = -8
+ERR_PENDING = -9
 
 _lock = threading.Lock()
 _lib = None
@@ -76,7 +77,7 @@ def _bind(L):
     L.fq_ste_bwd_mask.restype = i32
     L.fq_w12_fwd.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
     L.fq_w12_fwd.restype = i32
-    L.fq_sym_fwd_autocast.argtypes = [vp, vp, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp, sz, vp]
+    L.fq_sym_fwd_autocast.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, f32, f32, vp, vp, sz, vp, sz, vp]
     L.fq_sym_fwd_autocast.restype = i32
     L.fq_sym_fwd_pair.argtypes = [vp, vp, i64, i32, vp, vp, sz, vp, vp, i64, i32, vp, vp, sz, i64, i32, i32, i32, f32, f32, vp]
     L.fq_sym_fwd_pair.restype = i32
@@ -92,8 +93,6 @@ def _bind(L):
     L.fq_asym_export.restype = i32
     L.fq_sym_row_scales.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, f32, f32, vp, vp, sz, vp]
     L.fq_sym_row_scales.restype = i32
-    L.fq_qlinear_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp]
-    L.fq_qlinear_fwd.restype = i32
     L.fq_w12_fwd_rows.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
     L.fq_w12_fwd_rows.restype = i32
     L.fq_sym_fwd_multi.argtypes = [i32, ctypes.POINTER(FwdTensor), i64, i32, i32, i32, f32, f32, vp]
@@ -130,4 +129,6 @@ def check(rc, what):
         msg = lib().fq_last_error().decode(errors="replace")
         if rc in (-2,):  # FQ_ERR_BITS
             raise ValueError(f"{what}: {msg}")
+        if rc == ERR_PENDING:
+            raise RuntimeError(f"{what}: not launched -- {msg}")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libllmqat_fakequant.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("fq_api.hip", "fq_bf16.hip", "fq_f32.hip", "fq_f16.hip", "fq_export.hip", "fq_qlinear.hip", "fq_f64.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("fq_api.hip", "fq_bf16.hip", "fq_f32.hip", "fq_f16.hip", "fq_export.hip", "fq_f64.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fq_kernels.h", "fq_device.h", "fq_launch.h", "fq_dtype_impl.h", "fq_export.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "llmqat_fakequant.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",

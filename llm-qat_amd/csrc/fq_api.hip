@@ -135,17 +135,18 @@ FQ_API int fq_asym_fwd_train(const void* x, void* y, int64_t rows, int64_t cols,
     return rowwise<true>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, &mk);
 }
 
-FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int wide_out, float lo, float hi,
+FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t cols, int bits, int dtype, int sem, int wide_out, float lo, float hi,
                                float* row_bounds_out, void* mask_out, size_t mask_bytes, void* workspace, size_t workspace_bytes,
                                void* stream) {
     if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16)
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors (fp32 tensors are unaffected by autocast)");
     if (bits < 2 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [2, 31]", bits);
+    if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
     if (rows == 0 || cols == 0) return ok();
     if (!x || !y) return fail(FQ_ERR_NULL, "x / y must not be NULL");
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
-    const Consts c = make_consts(bits, dtype, FQ_SEM_DEVICE_EAGER);
+    const Consts c = make_consts(bits, dtype, sem);  // under autocast `sem` touches `max + 1e-6` only (everything behind it is fp32)
     RowArgs a{x, y, nullptr, nullptr, row_bounds_out, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, 0u, rows, 0, {}};
     if (mask_out) {
         if (!row_bounds_out) return fail(FQ_ERR_NULL, "a mask needs row_bounds_out too");
@@ -181,7 +182,7 @@ FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dty
         if (t[i].mask && t[i].mask_bytes < (size_t)t[i].rows * mrw * 8) return fail(FQ_ERR_WORKSPACE, "mask buffer too small");
         total += t[i].rows;
     }
-    const Consts c0 = make_consts(t[0].bits, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem);
+    const Consts c0 = make_consts(t[0].bits, dtype, sem);
     RowArgs a{t[0].x, t[0].y, nullptr, nullptr, t[0].row_bounds, total, cols, c0.sym, c0.asym, (uint64_t*)t[0].mask, mrw, host_rb(lo, dtype),
               host_rb(hi, dtype), ste_clip_key(host_rb(lo, dtype), host_rb(hi, dtype), dtype), t[0].rows, n - 1, {}};
     int64_t begin = t[0].rows;

@@ -249,13 +249,13 @@ template <int DT> __device__ __forceinline__ SymRow sym_row(float m, SymConst k)
 // ---- SymQuantizer as it executes under CUDA autocast (torch.autocast("cuda", bf16|fp16), LLM-QAT's --bf16 run) ----
 // `reciprocal` is on autocast's fp32 list, so  s = qmax / (max + 1e-6)  comes back as an fp32 tensor and every op
 // after it is promoted to fp32:  t1 = rb(max + 1e-6)  (the add still runs in the tensor dtype; the GPU keeps the
-// scalar in fp32),  s = (1/t1) * qmax,  idx = round(x * s),  y = idx / (s + 1e-6)  -- all fp32, output fp32.
+// scalar in fp32: c6 = 1e-6f unless the `sem` knob asks for the CPU's rounded scalar),  s = (1/t1) * qmax,  idx = round(x * s),  y = idx / (s + 1e-6)  -- all fp32, output fp32.
 // (measured on MI355X: tools/autocast_probe.py).  AC: 0 = no autocast, 1 = autocast, result rounded once to the
 // tensor dtype (what F.linear's autocast cast does to it next), 2 = autocast, fp32 result as the reference returns it.
-template <int DT> __device__ __forceinline__ SymRow sym_row_autocast(float m, float qmax) {
+template <int DT> __device__ __forceinline__ SymRow sym_row_autocast(float m, SymConst k) {
     SymRow r;
-    const float t1 = Ty<DT>::rb(m + 1e-6f);
-    r.s = (1.0f / t1) * qmax;
+    const float t1 = Ty<DT>::rb(m + k.c6);  // k.c6: 1e-6f (device-eager, what a real autocast run computes) or rb(1e-6) (`sem` knob)
+    r.s = (1.0f / t1) * k.qmax;
     r.t2 = r.s + 1e-6f;
     r.rinv = 1.0f / r.t2;
     r.mk = true;  // t2 = s + 1e-6 with s in [0, 2^31 * 1e6]: always inside div_exact()'s range (or NaN, which propagates)

@@ -75,7 +75,7 @@ static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
 template <int DT, int AC>
 static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     seal_slots(a);
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
@@ -152,7 +152,7 @@ template <int DT> int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t
 template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     seal_slots(a);
     constexpr int EPV = 16 / T::ESIZE;
     const bool pair = a.n_more > 0;  // several tensors in one launch: register kernels only
@@ -216,7 +216,7 @@ template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, 
 
 template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     constexpr int EPV = 16 / T::ESIZE;
     if (aligned16(g) && aligned16(x) && aligned16(gx) && n % EPV == 0) {
         const int64_t nvec = n / EPV;
@@ -241,7 +241,7 @@ template <int DT>
 int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
                     hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     constexpr int EPV = 16 / T::ESIZE;
     if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0))
         return launch_ste<DT>(g, x, gx, rows * cols, lo, hi, st);  // odd layout: plain path, same result
@@ -284,7 +284,7 @@ inline int64_t ste_layout(SteLaunch& L, bool allow_inplace) {
 
 template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape not served");
@@ -316,7 +316,7 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
 
 template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward applies to bf16 / fp16 inputs only");
     } else {
@@ -350,7 +350,7 @@ template <int DT>
 int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, float cv,
                hipStream_t st) {
     using T = Ty<DT>;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     constexpr int EPV = 16 / T::ESIZE;
     const bool vec = aligned16(w) && aligned16(out) && cols % EPV == 0;
     int64_t grid = vec ? (rows * (cols / EPV) + 255) / 256 : (rows * cols + 255) / 256;
@@ -370,7 +370,7 @@ template <int DT>
 int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     const int64_t nvec = cols / EPV;
     if (!(aligned16(w) && aligned16(out) && cols % EPV == 0 && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "fused 1-/2-bit branch: rows must be 16-byte aligned and fit the register kernels");
     if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);

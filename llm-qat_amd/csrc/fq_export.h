@@ -272,7 +272,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_export_kernel(Expor
             acc = T::absmax_acc(acc, r[i].w);
         }
         const float m = as_f(block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]));
-        sr = ac ? sym_row_autocast<DT>(m, a.sym.qmax) : sym_row<DT>(m, a.sym);
+        sr = ac ? sym_row_autocast<DT>(m, a.sym) : sym_row<DT>(m, a.sym);
         ub = m;
         lb = -m;
         top = sym_top_bin<DT>(m, sr, ac);
@@ -379,7 +379,7 @@ template <int DT, bool ASYM> __global__ __launch_bounds__(256) void row_export_g
             acc = acc > b ? acc : b;
         }
         const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
-        sr = ac ? sym_row_autocast<DT>(m, a.sym.qmax) : sym_row<DT>(m, a.sym);
+        sr = ac ? sym_row_autocast<DT>(m, a.sym) : sym_row<DT>(m, a.sym);
         ub = m;
         lb = -m;
         if (t == 0 && a.scales) {

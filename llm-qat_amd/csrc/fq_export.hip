@@ -35,7 +35,7 @@ template <int DT, bool ASYM, bool NTL> void launch_export_reg(const ExportArgs& 
 template <int DT, bool ASYM> int export_t(const ExportArgs& a, hipStream_t st) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
     const int64_t nvec = a.cols / EPV;
     // packed stores need the bins row to start on the store's natural boundary: EPV elements -> EPV*cbits/8 bytes
@@ -65,7 +65,7 @@ int export_entry(const void* x, void* bins, float* scales, int32_t* overflow, in
     if (!x) return fail(FQ_ERR_NULL, "x must not be NULL");
     if (container != BINS_NONE && !bins) return fail(FQ_ERR_NULL, "bins_out must not be NULL for this container");
     if (container == BINS_NONE && !scales && !bounds && !mask) return fail(FQ_ERR_NULL, "nothing to produce: scales_out, row_bounds_out and mask_out are all NULL");
-    const Consts c = make_consts(bits, dtype, autocast ? FQ_SEM_DEVICE_EAGER : sem);
+    const Consts c = make_consts(bits, dtype, sem);
     ExportArgs a{};
     a.x = x;
     a.bins = bins;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void w12_f64_kernel(const double* __restrict__
 }
 
 int launch_f64_rowwise(bool asym, const void* x, void* y, int32_t* idx, float* scale, int64_t rows, int64_t cols, int bits, int sem, hipStream_t st) {
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) return fail(FQ_ERR_UNSUPPORTED, "float64 tensors must be 8-byte aligned");
     if (asym) {
@@ -145,7 +145,7 @@ int launch_f64_rowwise(bool asym, const void* x, void* y, int32_t* idx, float* s
 }
 
 int launch_f64_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     int64_t grid = (n + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(ste_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const double*)g, (const double*)x, (double*)gx, n, (double)lo, (double)hi);
@@ -153,7 +153,7 @@ int launch_f64_ste(const void* g, const void* x, void* gx, int64_t n, float lo, 
 }
 
 int launch_f64_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, hipStream_t st) {
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     int64_t grid = (rows * cols + 255) / 256;
     if (grid > 16384) grid = 16384;
     if (w_bits == 1) hipLaunchKernelGGL(w12_f64_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, (const double*)w, (const double*)scale, (double*)out, rows, cols, scale_per_row);

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
         const uint32_t mbits = block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red[0]);
         const float m = as_f(mbits);
         if constexpr (AC == 0) sr = sym_row<DT>(m, symk);
-        else sr = sym_row_autocast<DT>(m, symk.qmax);
+        else sr = sym_row_autocast<DT>(m, symk);
         ub = m;
         lb = -m;
         if (t == 0) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
 #pragma unroll
     for (int i = 0; i < HPT; ++i) acc = T::absmax_acc(T::absmax_acc(acc, r[i].x), r[i].y);
     const float m = as_f(block_reduce<OpMaxU, NW>(T::absmax_finish(acc), red));
-    const SymRow sr = sym_row_autocast<DT>(m, qmax);
+    const SymRow sr = sym_row_autocast<DT>(m, SymConst{qmax, a.sym.c6});
     if (t == 0 && bnd) {
         bnd[2 * row] = m;
         bnd[2 * row + 1] = -m;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
         }
         const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
         if constexpr (AC == 0) sr = sym_row<DT>(m, a.sym);
-        else sr = sym_row_autocast<DT>(m, a.sym.qmax);
+        else sr = sym_row_autocast<DT>(m, a.sym);
         if (t == 0) {
             if (a.scale) a.scale[row] = sr.s;
             if (a.bounds) {
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(TP_THREADS) void apply_autocast_kernel(RowArgs a, c
     int64_t cend = (chunk + 1) * CH;
     if (cend > a.cols) cend = a.cols;
     const float m = as_f(ws[2 * row]);
-    const SymRow sr = sym_row_autocast<DT>(m, a.sym.qmax);
+    const SymRow sr = sym_row_autocast<DT>(m, a.sym);
     if (chunk == 0 && threadIdx.x == 0 && a.bounds) {
         a.bounds[2 * row] = m;
         a.bounds[2 * row + 1] = -m;

@@ -19,9 +19,17 @@ namespace fq {
 FQ_HIDDEN int fail(int code, const char* fmt, ...);
 FQ_HIDDEN int ok();
 
-// hipLaunchKernelGGL returns nothing, and hipGetLastError() reports the calling thread's LAST error, whoever caused it.
-// Every launch function therefore drains a pending (foreign) error first and reads the status of its own launches after.
-inline void clear_stale_error() { (void)hipGetLastError(); }
+// hipLaunchKernelGGL returns nothing, and hipGetLastError() reports the calling thread's LAST error, whoever caused it.  A
+// launch function therefore PEEKS first: an error that is already pending belongs to an earlier launch or to another
+// library, so it is reported as such (FQ_ERR_PENDING), left in place for its owner to see, and nothing is launched on top of
+// a context in an unknown state.  (Rounds 1-3 drained it silently: that hid other people's failures.)  With nothing pending,
+// whatever hipGetLastError() returns after the launches is this call's own.
+inline int pending_error() {
+    const hipError_t e = hipPeekAtLastError();
+    return e == hipSuccess ? 0
+                           : fail(FQ_ERR_PENDING, "a HIP error was already pending on this thread before this call (an earlier launch or another "
+                                  "library raised it; it is not cleared here): %s", hipGetErrorString(e));
+}
 inline int launch_result() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? ok() : fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

@@ -24,7 +24,12 @@ def set_semantics(name):
 
 
 def get_semantics():
-    return next(k for k, v in _SEM_NAMES.items() if v == _semantics)
+    return "device_eager" if _semantics == _lib.SEM_DEVICE_EAGER else "cpu_eager"
+
+
+# Under torch.autocast("cuda") the reference runs on the device by definition, where ATen keeps the `+ 1e-6` scalar in fp32: the
+# autocast arithmetic is always launched with device-eager scalars (the C ABI takes `sem` there too: the parity tests drive both).
+_SEM_AUTOCAST = _lib.SEM_DEVICE_EAGER
 
 
 def rows_cols(shape, layerwise):
@@ -266,7 +271,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
             if mbytes:
                 side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
                 sp = side.data_ptr()
-                rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
+                rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _SEM_AUTOCAST, int(wide), float(lo), float(hi),
                                            sp, sp + rows * 8, mbytes, ws_ptr, ws_bytes, st)
                 got = "mask"
         if rc == _lib.ERR_UNSUPPORTED:
@@ -275,7 +280,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
             if train in ("mask", "bounds"):
                 side = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
                 bptr, got = side.data_ptr(), "bounds"
-            rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, int(wide), float(lo), float(hi),
+            rc = L.fq_sym_fwd_autocast(xc.data_ptr(), y.data_ptr(), rows, cols, int(num_bits), code, _SEM_AUTOCAST, int(wide), float(lo), float(hi),
                                        bptr, None, 0, ws_ptr, ws_bytes, st)
     _lib.check(rc, "sym_quantize[autocast]")
     if xc is not x:
@@ -315,7 +320,7 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     with _DeviceOf(w):
         rc = L.fq_sym_fwd_pair(w.data_ptr(), wq.data_ptr(), rows_w, int(w_bits), pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
                                x.data_ptr(), xq.data_ptr(), rows_x, int(a_bits), px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
-                               cols, code, _semantics, (2 if wide else 1) if ac else 0, float(lo), float(hi), _stream(w))
+                               cols, code, _SEM_AUTOCAST if ac else _semantics, (2 if wide else 1) if ac else 0, float(lo), float(hi), _stream(w))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "quantize_pair")
@@ -393,7 +398,7 @@ def multi_forward(tensors, bits, need, lo, hi):
         sp = sd.data_ptr() if sd is not None else None
         arr[i] = _lib.FwdTensor(t.data_ptr(), y.data_ptr(), rows[i], int(bits[i]), sp, sp + rows[i] * 8 if sp else None, mbytes[i] if sp else 0)
     with _DeviceOf(t0):
-        rc = _lib.lib().fq_sym_fwd_multi(n, arr, cols, code, _semantics, 1 if ac else 0, float(lo), float(hi), _stream(t0))
+        rc = _lib.lib().fq_sym_fwd_multi(n, arr, cols, code, _SEM_AUTOCAST if ac else _semantics, 1 if ac else 0, float(lo), float(hi), _stream(t0))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "quantize_multi")
@@ -617,7 +622,7 @@ def _export(kind, x, num_bits, layerwise, container, autocast):
     with _DeviceOf(x):
         if kind == "sym":
             rc = L.fq_sym_export(xc.data_ptr(), raw.data_ptr(), scales.data_ptr(), overflow.data_ptr(), rows, cols, int(num_bits), cc, code,
-                                 _semantics, 1 if autocast else 0, _stream(x))
+                                 _SEM_AUTOCAST if autocast else _semantics, 1 if autocast else 0, _stream(x))
         else:
             rc = L.fq_asym_export(xc.data_ptr(), raw.data_ptr(), scales.data_ptr(), overflow.data_ptr(), rows, cols, int(num_bits), cc, code,
                                   _semantics, _stream(x))
@@ -654,46 +659,7 @@ def sym_row_scales(x, num_bits, layerwise=False, autocast=None):
     xc = x if x.is_contiguous() else x.contiguous()
     scales = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
     with _DeviceOf(x):
-        rc = _lib.lib().fq_sym_row_scales(xc.data_ptr(), scales.data_ptr(), rows, cols, int(num_bits), code, _semantics, 1 if ac else 0,
+        rc = _lib.lib().fq_sym_row_scales(xc.data_ptr(), scales.data_ptr(), rows, cols, int(num_bits), code, _SEM_AUTOCAST if ac else _semantics, 1 if ac else 0,
                                           -2.0, 2.0, None, None, 0, _stream(x))
     _lib.check(rc, "sym_row_scales")
     return scales
-
-
-def qlinear_forward(x, weight, w_bits, a_bits, quantize_x=True, quantize_w=True, autocast=None, dump=False, ablation=0,
-                    x_scales=None, w_scales=None):
-    """QuantizeLinear's no-grad forward with the fake-quant applied while the GEMM loads its operands (fq_qlinear_fwd):
-    out = fq(x) @ fq(weight).T, bf16.  quantize_x / quantize_w = False multiplies that operand as it is (already
-    fake-quantized by a sibling, or w_bits >= 32).  Scale pre-passes (fq_sym_row_scales) run here unless given.
-    -> out, or (out, staged_x, staged_w) with dump=True (the operand tiles exactly as the MFMAs saw them).
-    Returns None when the shape / alignment is not served (the caller uses the unfused path)."""
-    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or not (x.is_cuda and weight.is_cuda) or weight.dim() != 2:
-        return None
-    k = weight.shape[1]
-    if x.shape[-1] != k or not (x.is_contiguous() and weight.is_contiguous()) or x.numel() == 0:
-        return None
-    n = weight.shape[0]
-    m = x.numel() // k
-    ac = autocast_active(x) if autocast is None else bool(autocast)
-    L = _lib.lib()
-    code = _lib.DTYPE_BF16
-    with _DeviceOf(x):
-        st = _stream(x)
-        if quantize_x and x_scales is None:
-            x_scales = torch.empty((m, 2), dtype=torch.float32, device=x.device)
-            _lib.check(L.fq_sym_row_scales(x.data_ptr(), x_scales.data_ptr(), m, k, int(a_bits), code, _semantics, 1 if ac else 0, -2.0, 2.0,
-                                           None, None, 0, st), "sym_row_scales")
-        if quantize_w and w_scales is None:
-            w_scales = torch.empty((n, 2), dtype=torch.float32, device=x.device)
-            _lib.check(L.fq_sym_row_scales(weight.data_ptr(), w_scales.data_ptr(), n, k, int(w_bits), code, _semantics, 1 if ac else 0, -2.0, 2.0,
-                                           None, None, 0, st), "sym_row_scales")
-        out = torch.empty(x.shape[:-1] + (n,), dtype=torch.bfloat16, device=x.device)
-        dx = torch.empty_like(x) if dump else None
-        dw = torch.empty_like(weight) if dump else None
-        rc = L.fq_qlinear_fwd(x.data_ptr(), x_scales.data_ptr() if quantize_x else None, weight.data_ptr(), w_scales.data_ptr() if quantize_w else None,
-                              out.data_ptr(), m, k, n, code, 1 if ac else 0, dx.data_ptr() if dump else None, dw.data_ptr() if dump else None,
-                              int(ablation), st)
-    if rc == _lib.ERR_UNSUPPORTED:
-        return None
-    _lib.check(rc, "qlinear_forward")
-    return (out, dx, dw) if dump else out

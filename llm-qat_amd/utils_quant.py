@@ -11,6 +11,7 @@ so `models/modeling_llama_quant.py` (which imports them by name, :51) and everyt
 (`train.py`, `utils/kd_trainer.py`) run unchanged.  The eager ATen op chains are replaced by
 single-pass HIP kernels for gfx950 (see INTEGRATION.md for the one-line switch).
 """
+import logging
 import os
 import sys
 import threading
@@ -45,24 +46,42 @@ def get_backward_mode():
     return _BACKWARD_MODE
 
 
-_clip_memo = {}
-
-
 def _clip_pair(clip_val):
-    """(lo, hi) of a clip tensor as Python floats.  The model keeps its clip tensors alive (act_clip_val_k / _v are attributes,
-    modeling_llama_quant.py:251-252), so the host read is memoised per tensor object and version (a weak reference guards id reuse)."""
+    """(lo, hi) of a clip tensor as Python floats, read from the tensor on every call, as the reference does (:85-86).  The model's
+    clip tensors live on the CPU (plain attributes, modeling_llama_quant.py:251-252): reading two floats costs ~1 us.  (Rounds 2-3
+    memoised the pair per tensor object and version; a write through `.data` goes past that version counter)"""
     if clip_val is _CLIP:
         return -2.0, 2.0
-    ent = _clip_memo.get(id(clip_val))
-    if ent is not None and ent[0]() is clip_val and ent[1] == clip_val._version:
-        return ent[2]
-    lo, hi = clip_val.tolist()[:2] if clip_val.dim() else (clip_val.item(),) * 2
-    pair = (float(lo), float(hi))
-    if clip_val.device.type == "cpu":   # (a device tensor's .tolist() synchronises; do not hide that by caching across in-place updates we cannot see coming)
-        if len(_clip_memo) > 64:
-            _clip_memo.clear()
-        _clip_memo[id(clip_val)] = (weakref.ref(clip_val), clip_val._version, pair)
-    return pair
+    if clip_val.dim():
+        lo, hi = clip_val.tolist()[:2]
+        return float(lo), float(hi)
+    v = float(clip_val.item())
+    return v, v
+
+
+# ---- counters of what the stateful host logic did (llm_qat_amd.stats()): every optimisation below that can silently fall back says so here
+_stats = {}
+
+
+def _count(name, n=1):
+    _stats[name] = _stats.get(name, 0) + n
+
+
+def stats(reset=False):
+    """-> dict of counters since import / the last reset:
+      pair_launch / single_launch        QuantizeLinear forwards served by one two-tensor launch / by separate calls
+      act_share_hit / act_share_miss     sibling projections that found their input already fake-quantized / that quantized it
+      kv_pair_launch / kv_pair_hit / kv_pair_discarded / kv_pair_learned_off
+                                         K+V speculation at the unchanged hooks: launched, V served from it, V result thrown away,
+                                         call signatures that stopped pairing after a wrong guess
+      wcache_fill / wcache_hit           weight-quant cache (opt-in)
+      inplace_taken / inplace_refused:<reason>
+                                         weight gradients masked where they stand vs copied, by the guard's reason
+                                         (uncalibrated, disabled, storage, anomaly, py_refs, cxx_refs, storage_refs, base_refs)"""
+    out = dict(_stats)
+    if reset:
+        _stats.clear()
+    return out
 
 
 class _FakeQuantFunction(torch.autograd.Function):
@@ -136,7 +155,7 @@ class _FakeQuantFunction(torch.autograd.Function):
             input, clip_val = ctx.saved_tensors
             return compiled.fake_quant_bwd(grad_output, input, clip_val), None, None, None
         inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
-        _bwd_epoch[0] += 1  # invalidates activation-sharing entries made before this backward started
+        _backward_started()
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
@@ -271,6 +290,12 @@ def inplace_weight_grad(flag=True):
 #    ::test_inplace_weight_gradient_is_guarded).  What a hook is handed is the gradient BEFORE this node's mask, as with the
 #    reference's clone -- hooks run before the node.
 _ref_base = {}
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)   # holders of the StorageImpl itself (aliases made without view tracking)
+_log = logging.getLogger("llm_qat_amd")
+
+
+def _storage_holders(g):
+    return _storage_use_count(g.untyped_storage()._cdata)
 
 
 def _grad_counts(g):
@@ -283,9 +308,11 @@ def _base_counts(g):
 
 
 def _calibrate_grad_counts():
-    """Reference counts of a gradient as it arrives in a backward written like the ones below, with nobody else holding it
-    ("named": backward(ctx, gw, gx); "star": backward(ctx, *grads), read by index).  Run once at import on tiny CPU tensors,
-    through the same decorators, F.linear producing the gradient as in QuantizeLinear."""
+    """Reference counts of a gradient as it arrives in a backward written like the ones below (backward(ctx, gw, gx)), with nobody
+    else holding it.  Run once at import on tiny CPU tensors, through the same decorators, F.linear producing the gradient as in
+    QuantizeLinear.  Plus the holders of a StorageImpl for a tensor that owns it alone and for a view of a temporary (F.linear's
+    wgrad arrives as the latter): an alias made WITHOUT view tracking -- `g.data`, `set_`, aten.alias under a key exclusion -- has
+    its own TensorImpl and no `_base`, so only the storage's own count shows it."""
     class _Named(torch.autograd.Function):
         @staticmethod
         def forward(ctx, w, x):
@@ -297,24 +324,14 @@ def _calibrate_grad_counts():
             _ref_base["named"] = _grad_counts(gw)
             return gw, gx
 
-    class _Star(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, w, x):
-            return w * 1.0, x * 1.0
-
-        @staticmethod
-        @once_differentiable
-        def backward(ctx, *grads):
-            _ref_base["star"] = _grad_counts(grads[0])
-            return grads
-
     _ref_base["base"] = _base_counts(torch.zeros(2, 4).view(4, 2))   # a view of a temporary nobody else holds
+    _ref_base["storage_plain"] = _storage_holders(torch.zeros(8))
+    _ref_base["storage_view"] = _storage_holders(torch.zeros(2, 4).view(4, 2))
     with torch.inference_mode(False), torch.enable_grad():
-        for fn in (_Named, _Star):
-            w = torch.zeros(2, 4, requires_grad=True)
-            x = torch.zeros(3, 4, requires_grad=True)
-            wq, xq = fn.apply(w, x)
-            nn.functional.linear(xq, wq).sum().backward()
+        w = torch.zeros(2, 4, requires_grad=True)
+        x = torch.zeros(3, 4, requires_grad=True)
+        wq, xq = _Named.apply(w, x)
+        nn.functional.linear(xq, wq).sum().backward()
 
 
 def _owns_storage(g):
@@ -322,18 +339,36 @@ def _owns_storage(g):
     return g.is_contiguous() and g.storage_offset() == 0 and g.untyped_storage().nbytes() == g.numel() * g.element_size()
 
 
-def _inplace_ok(g, style="named"):
+def _refuse(reason):
+    _count("inplace_refused:" + reason)
+    return False
+
+
+def _inplace_ok(g):
     """may this backward mask grad_output `g` where it stands?  Called directly from the backward with the argument itself
-    (`_inplace_ok(gw)` / `_inplace_ok(grads[i], "star")`) so that the reference count compares with the calibration."""
-    base = _ref_base.get(style)
-    if base is None or not _owns_storage(g) or torch.is_anomaly_enabled():
-        return False
-    if sys.getrefcount(g) > base[0] or g._use_count() > base[1]:
-        return False
+    (`_inplace_ok(gw)`) so that the reference count compares with the calibration.  Every refusal is counted by reason (stats())."""
+    base = _ref_base.get("named")
+    if base is None:
+        return _refuse("uncalibrated")
+    if sys.getrefcount(g) > base[0]:
+        return _refuse("py_refs")
+    if g._use_count() > base[1]:
+        return _refuse("cxx_refs")
+    if not _owns_storage(g):
+        return _refuse("storage")
+    if torch.is_anomaly_enabled():
+        return _refuse("anomaly")
     if g._base is None:
-        return True
-    bc, bb = _base_counts(g), _ref_base["base"]  # F.linear's wgrad arrives as a view of a temporary: fine if nobody else can reach it
-    return bc[0] <= bb[0] and bc[1] <= bb[1]
+        if _storage_holders(g) > _ref_base["storage_plain"]:
+            return _refuse("storage_refs")
+    else:
+        bc, bb = _base_counts(g), _ref_base["base"]  # F.linear's wgrad arrives as a view of a temporary: fine if nobody else can reach it
+        if bc[0] > bb[0] or bc[1] > bb[1]:
+            return _refuse("base_refs")
+        if _storage_holders(g) > _ref_base["storage_view"]:
+            return _refuse("storage_refs")
+    _count("inplace_taken")
+    return True
 
 
 _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every call (:198, :245)
@@ -376,21 +411,38 @@ def enable_weight_quant_cache(flag=True, persistent=False):
     _WEIGHT_CACHE_PERSISTENT = bool(flag) and bool(persistent)
 
 
+_MODE_CODE = {"mask": 0, "bounds": 1, "plain": 2}
+
+
+def _state_word(x):
+    """everything ambient that decides which arithmetic / data flow a call takes, folded into one int (part of the cache keys)"""
+    return (_MODE_CODE[_BACKWARD_MODE] + 4 * ops._semantics + (8 if torch.is_grad_enabled() else 0)
+            + (16 if ops.autocast_active(x) else 0))
+
+
 def _act_key(quantizer, x, num_bits, layerwise):
-    return (quantizer, num_bits, layerwise, torch.is_grad_enabled(), _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(x))
+    return (quantizer, num_bits, layerwise, _state_word(x))
 
 
-def _act_lookup(key, x, want_leader=False):
+def _backward_started():
+    """every fake-quant backward calls this first: results remembered before it (shared activations, a pending V of the K/V
+    hooks) are never handed out afterwards -- their graphs may already be consumed"""
+    _bwd_epoch[0] += 1
+    if getattr(_tls, "kv_stash", None) is not None:
+        _kv_discard()
+
+
+def _act_lookup(key, x):
     cache = getattr(_tls, "act", None)
     ent = cache.get(key) if cache else None
     if ent is not None:
-        rin, ver_in, y, ver_out, epoch, leader = ent
+        rin, ver_in, y, ver_out, epoch = ent
         if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0]:
-            return (y, leader() if leader is not None else None) if want_leader else y
-    return (None, None) if want_leader else None
+            return y
+    return None
 
 
-def _act_store(key, x, y, leader=None):
+def _act_store(key, x, y):
     cache = getattr(_tls, "act", None)
     if cache is None:
         cache = _tls.act = {}
@@ -400,19 +452,22 @@ def _act_store(key, x, y, leader=None):
         if ent is not None and ent[0] is ref:
             del cache[key]
 
-    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0], weakref.ref(leader) if leader is not None else None)
+    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0])
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
     if quantizer is SymQuantizer:
         quantizer = _SymQuantizerOperand
-    if not _SHARE_ACT:
+    if not _SHARE_ACT or x.is_inference():   # (inference tensors have no version counter: nothing is remembered about them)
         return quantizer.apply(x, _CLIP, num_bits, layerwise)
     key = _act_key(quantizer, x, num_bits, layerwise)
     y = _act_lookup(key, x)
     if y is None:
+        _count("act_share_miss")
         y = quantizer.apply(x, _CLIP, num_bits, layerwise)
         _act_store(key, x, y)
+    else:
+        _count("act_share_hit")
     return y
 
 
@@ -425,21 +480,6 @@ _PAIR = os.environ.get("LLMQAT_AMD_PAIR_OPERANDS", "1") != "0"
 def pair_operands(flag=True):
     global _PAIR
     _PAIR = bool(flag)
-
-
-# 4. (opt-in) When no backward will run -- eval, or the first pass of a reentrant-checkpointed layer
-#    (modeling_llama_quant.py:732-747) -- the weight's fake-quant can be applied inside the GEMM's operand staging
-#    (fq_qlinear_fwd) instead of writing the quantized weight to HBM first.  MEASURED SLOWER than the default on MI355X
-#    (profiles/r02_qlinear_bench*.json, DESIGN.md §10: the staged fake-quant is re-done by every tile that shares the
-#    operand and does not hide under the MFMAs; hipBLASLt's GEMM is also faster than this kernel's), so it is OFF by
-#    default: LLMQAT_AMD_FUSED_QLINEAR=1 / fuse_qlinear(True) turn it on.  Operand values are bit-identical either way;
-#    the product differs by fp32 accumulation order only.
-_FUSED_QLINEAR = os.environ.get("LLMQAT_AMD_FUSED_QLINEAR", "0") == "1"
-
-
-def fuse_qlinear(flag=True):
-    global _FUSED_QLINEAR
-    _FUSED_QLINEAR = bool(flag)
 
 
 class _PairNode(torch.autograd.Function):
@@ -466,7 +506,7 @@ class _PairNode(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gw, gx):
         inplace_w = ctx.inplace_w and _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
-        _bwd_epoch[0] += 1
+        _backward_started()
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lo, hi = ctx.clip
         side_w, side_x = ctx.saved_tensors
@@ -485,60 +525,6 @@ class _PairNode(torch.autograd.Function):
             return None, None, None, None, None
         ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=inplace_w)
         return ow, ox, None, None, None
-
-
-# 5. Sibling projections share their input (q/k/v: modeling_llama_quant.py:313,317,318; gate/up: :235) and all reduce over
-#    the same `in`: the first of them to run (the "leader") quantizes its weight, the shared input AND the siblings'
-#    weights in ONE launch (fq_sym_fwd_multi, up to 4 tensors), and one backward launch returns all their gradients
-#    (autograd runs a node once every output's gradient has arrived).  Siblings are learned, not declared: a module that
-#    finds its activation already quantized by another module registers with that module, and is served from the next
-#    forward on.  A prefetched weight is used only if the weight is still the very tensor (identity, version, storage) it
-#    was computed from, in the same grad / autocast / backward mode, with no fake-quant backward in between.
-#    OPT-IN since round 3 (LLMQAT_AMD_GROUP_SIBLINGS=1 / group_siblings(True)): measured on the two-layer 7B-sized step it buys
-#    nothing end to end (16.03 vs 16.02 ms; checkpointing 20.35 vs 20.49 ms, profiles/r02_model_step_bench_autocast.json -- the
-#    GEMMs hide the launch count), so the default path carries no learned, stateful dispatch; operand pairing (point 3) stays.
-_GROUP = os.environ.get("LLMQAT_AMD_GROUP_SIBLINGS", "0") == "1"
-_MAX_FOLLOWERS = 2
-
-
-def group_siblings(flag=True):
-    global _GROUP
-    _GROUP = bool(flag)
-
-
-class _MultiNode(torch.autograd.Function):
-    """Autograd node over the results of one ops.multi_forward launch."""
-
-    @staticmethod
-    def forward(ctx, res, clip, *tensors):
-        ys, sides, ctx.rows, ctx.cols = res
-        ctx.dtype, ctx.clip = tensors[0].dtype, clip
-        ctx.set_materialize_grads(False)
-        ctx.save_for_backward(*sides)
-        outs = tuple(y.view_as(y) for y in ys)
-        nd = [o for o, need in zip(outs, ctx.needs_input_grad[2:]) if not need]
-        if nd:
-            ctx.mark_non_differentiable(*nd)
-        return outs
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, *grads):
-        # tensor 1 is the shared input; the others are weights, whose gradients may be masked where they stand (guarded)
-        inplace = [_INPLACE_WGRAD and i != 1 and grads[i] is not None and _inplace_ok(grads[i], "star") for i in range(len(grads))]
-        _bwd_epoch[0] += 1
-        lo, hi = ctx.clip
-        gs = []
-        for i, need in enumerate(ctx.needs_input_grad[2:]):
-            if grads[i] is None or not need:
-                gs.append(None)
-            elif grads[i].dtype == ctx.dtype:
-                gs.append(grads[i])
-            else:
-                gs.append(grads[i].to(ctx.dtype))
-                inplace[i] = _INPLACE_WGRAD and i != 1   # a fresh tensor of our own
-        outs = ops.multi_backward(gs, list(ctx.saved_tensors), ctx.rows, ctx.cols, lo, hi, inplace=inplace)
-        return (None, None) + tuple(outs)
 
 
 def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
@@ -589,6 +575,8 @@ def pair_kv_hooks(flag=True):
 
 def _note_output(out):
     """QuantizeLinear.forward: remember (weakly) the last few outputs of this thread, in order"""
+    if out.is_inference():   # no version counter (torch.inference_mode): such outputs are never paired
+        return
     rec = getattr(_tls, "outs", None)
     if rec is None:
         rec = _tls.outs = []
@@ -598,19 +586,34 @@ def _note_output(out):
 
 
 def _kv_state(clip_val, num_bits):
-    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops.get_semantics(), _bwd_epoch[0])
+    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops._semantics, _bwd_epoch[0])
+
+
+_kv_off = set()   # call signatures whose speculation was thrown away once: they stop pairing
+
+
+def _kv_discard():
+    """a V result nobody asked for: forget it (and its graph + side buffers), and stop guessing for that call signature"""
+    stash, _tls.kv_stash = _tls.kv_stash, None
+    _count("kv_pair_discarded")
+    if stash[4] not in _kv_off:
+        _kv_off.add(stash[4])
+        _count("kv_pair_learned_off")
 
 
 def _kv_hook(x, clip_val, num_bits):
     """-> the fake-quantized x if it is served from / by a K+V pair launch, else None (the ordinary single call runs)"""
-    if not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 2 <= num_bits < 32 and x.dim() <= 3) or torch.compiler.is_compiling():
+    if (not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 2 <= num_bits < 32 and x.dim() <= 3) or x.is_inference()
+            or torch.compiler.is_compiling()):
         return None
     stash = getattr(_tls, "kv_stash", None)
     if stash is not None:
-        _tls.kv_stash = None
-        ref, ver, vq, state = stash
+        ref, ver, vq, state, sig = stash
         if ref() is x and ver == x._version and state == _kv_state(clip_val, num_bits):
+            _tls.kv_stash = None
+            _count("kv_pair_hit")
             return vq   # V: quantized together with K a moment ago
+        _kv_discard()
     rec = getattr(_tls, "outs", None)
     if not rec:
         return None
@@ -623,15 +626,24 @@ def _kv_hook(x, clip_val, num_bits):
                     or not v.is_contiguous() or not x.is_contiguous() or v.requires_grad != x.requires_grad):
                 return None
             lo, hi = _clip_pair(clip_val)
+            sig = (x.shape, x.dtype, num_bits, lo, hi)
+            if sig in _kv_off:
+                return None
             grad = torch.is_grad_enabled()
             need = grad and x.requires_grad
             res = ops.pair_forward(x, v, num_bits, num_bits, lo, hi, need, need, wide=True)
             if res is None:
                 return None
+            _count("kv_pair_launch")
             kq, vq = _PairNode.apply(x, v, res, (lo, hi)) if need else (res[0], res[1])
-            _tls.kv_stash = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits))
+            _tls.kv_stash = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits), sig)
             return kq
     return None
+
+
+def reset_learned_state():
+    """forget what the host logic has learned about call sites (today: K/V signatures that stopped pairing)"""
+    _kv_off.clear()
 
 
 def conservative(flag=True):
@@ -647,8 +659,6 @@ def conservative(flag=True):
     inplace_weight_grad(not flag)
     if flag:
         enable_weight_quant_cache(False)
-        group_siblings(False)
-        fuse_qlinear(False)
         fuse_low_bit_mean(False)
 
 
@@ -695,7 +705,7 @@ class _PrecomputedAct(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        _bwd_epoch[0] += 1
+        _backward_started()
         (side,) = ctx.saved_tensors
         lo, hi = ctx.clip
         rows, cols = ctx.rows_cols
@@ -730,22 +740,14 @@ class QuantizeLinear(nn.Linear):
             sc = absmean if self.w_bits == 1 else 2 * absmean
         return _LowBitWeight.apply(w, sc, self.w_bits)
 
-    def _prefetch_key(self):
-        w = self.weight
-        return (id(w), w._version, w.data_ptr(), self.w_bits, torch.is_grad_enabled() and w.requires_grad, _BACKWARD_MODE, ops.get_semantics(),
-                ops.autocast_active(w), _bwd_epoch[0])
-
     def _wcache_key(self):
         w = self.weight
-        return (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _BACKWARD_MODE, ops.get_semantics(), ops.autocast_active(w))
+        return (id(w), w._version, w.data_ptr(), self.w_bits, self.weight_layerwise, _MODE_CODE[_BACKWARD_MODE] + 4 * ops._semantics + (16 if ops.autocast_active(w) else 0))
 
     def _quantized_weight(self):
         w = self.weight
-        pre = self.__dict__.pop("_fq_prefetch", None)
-        if pre is not None and pre[0] == self._prefetch_key():
-            return pre[1]  # the leader of this sibling group quantized this weight in its own launch
         ac = ops.autocast_active(w)
-        if not _WEIGHT_CACHE or not w.is_cuda or (ac and not ops.autocast_narrow_ok(w)):
+        if not _WEIGHT_CACHE or not w.is_cuda or w.is_inference() or (ac and not ops.autocast_narrow_ok(w)):
             # (an fp16 weight inside autocast(bf16), or the reverse, gets the reference's fp32 result and an fp32 gradient:
             # the plain node handles both dtypes; the cache's node works in the weight's dtype only)
             return _SymQuantizerWeight.apply(w, _CLIP, self.w_bits, self.weight_layerwise)
@@ -753,6 +755,7 @@ class QuantizeLinear(nn.Linear):
         ent = getattr(self, "_fq_wcache", None)
         if ent is not None and ent[0] == key:
             cached = ent[1]
+            _count("wcache_hit")
             if not _WEIGHT_CACHE_PERSISTENT:
                 self._fq_wcache = None  # second use within the step (the checkpoint recompute): done with it
         else:
@@ -775,6 +778,7 @@ class QuantizeLinear(nn.Linear):
                     y, bounds = ops.sym_quantize(w, self.w_bits, self.weight_layerwise, want_bounds=True)
             cached = (y, bounds, mask, rc)
             self._fq_wcache = (key, cached)
+            _count("wcache_fill")
         if torch.is_grad_enabled() and w.requires_grad:
             return _ReuseQuantizedWeight.apply(w, cached, _CLIP)  # launches nothing; backward = the ordinary STE
         return cached[0]
@@ -783,6 +787,8 @@ class QuantizeLinear(nn.Linear):
         """weight and input in one launch; None when the pair is not applicable (then the ordinary two calls run)"""
         if not (_PAIR and _BACKWARD_MODE == "mask" and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
             return None
+        if input_.is_inference() or self.weight.is_inference():
+            return None   # no version counters under torch.inference_mode: nothing is paired, shared or remembered
         wkey = None
         if _WEIGHT_CACHE:
             # With the weight cache on, the FIRST use of a weight in a step still shares a launch with its input and fills the
@@ -795,19 +801,9 @@ class QuantizeLinear(nn.Linear):
             return None
         key = _act_key(_SymQuantizerOperand, input_, self.a_bits, False) if _SHARE_ACT else None
         if key is not None:
-            y, leader = _act_lookup(key, input_, want_leader=True)
-            if y is not None:
-                # a sibling projection already quantized this activation: only the weight is left to do -- and next time
-                # that sibling (the leader) does this weight too, in its own launch
-                if _GROUP and leader is not None and leader is not self:
-                    fl = leader.__dict__.setdefault("_fq_followers", [])
-                    if len(fl) < _MAX_FOLLOWERS and all(r() is not self for r, _ in fl):
-                        fl.append((weakref.ref(self), leader.weight._version))
-                return None
+            if _act_lookup(key, input_) is not None:
+                return None   # a sibling projection already quantized this activation: only the weight is left to do
         grad = torch.is_grad_enabled()
-        multi = self._multi_forward(input_, key, grad) if (_GROUP and wkey is None and key is not None and self.__dict__.get("_fq_followers")) else None
-        if multi is not None:
-            return multi
         res = ops.pair_forward(self.weight, input_, self.w_bits, self.a_bits, -2.0, 2.0,
                                (grad and self.weight.requires_grad) or wkey is not None, grad and input_.requires_grad)
         if res is None:
@@ -820,75 +816,21 @@ class QuantizeLinear(nn.Linear):
             side_w, side_x = res[2], res[3]
             cached = (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:], ops.rows_cols(tuple(self.weight.shape), False))
             self._fq_wcache = (wkey, cached)
+            _count("wcache_fill")
+            _count("pair_launch")
             wq = _ReuseQuantizedWeight.apply(self.weight, cached, _CLIP) if (grad and self.weight.requires_grad) else res[0]
             xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if (grad and input_.requires_grad) else res[1]
             if key is not None:
-                _act_store(key, input_, xq, leader=self)
+                _act_store(key, input_, xq)
             return wq, xq
+        _count("pair_launch")
         if grad and (self.weight.requires_grad or input_.requires_grad):
             wq, xq = _PairNode.apply(self.weight, input_, res, (-2.0, 2.0), True)
         else:
             wq, xq = res[0], res[1]
         if key is not None:
-            _act_store(key, input_, xq, leader=self)
+            _act_store(key, input_, xq)
         return wq, xq
-
-    def _multi_forward(self, input_, key, grad):
-        """this module's weight + the shared input + the weights of the sibling projections that registered as followers,
-        one launch (ops.multi_forward); the followers find their quantized weight in `_fq_prefetch`.  None: not served."""
-        w = self.weight
-        fols, keep = [], []
-        for r, reg_version in self._fq_followers:
-            f = r()
-            if f is None:
-                continue
-            keep.append((r, reg_version))
-            # A group learned during a forward becomes active in grad mode only once the leader's weight has changed since
-            # (an optimizer step lies in between): a checkpointed forward and its recompute must build the same graph, so
-            # the switch from "pair + separate weights" to "one launch" may not fall between the two.  Without grad there
-            # is no graph: active at once.
-            if grad and w._version == reg_version:
-                continue
-            if (3 <= f.w_bits < 32 and f.a_bits == self.a_bits and not f.weight_layerwise and not f.act_layerwise
-                    and getattr(f, "act_quantizer", None) is SymQuantizer and f.weight.dtype == w.dtype and f.weight.device == w.device
-                    and f.weight.dim() == 2 and f.weight.shape[1] == w.shape[1] and f.weight.is_contiguous()):
-                fols.append(f)
-        self._fq_followers = keep  # dead siblings drop out
-        if not fols:
-            return None
-        tensors = [w, input_] + [f.weight for f in fols]
-        bits = [self.w_bits, self.a_bits] + [f.w_bits for f in fols]
-        need = [grad and w.requires_grad, grad and input_.requires_grad] + [grad and f.weight.requires_grad for f in fols]
-        res = ops.multi_forward(tensors, bits, need, -2.0, 2.0)
-        if res is None:
-            return None
-        outs = _MultiNode.apply(res, (-2.0, 2.0), *tensors) if any(need) else tuple(res[0])
-        for f, o in zip(fols, outs[2:]):
-            f._fq_prefetch = (f._prefetch_key(), o)
-        _act_store(key, input_, outs[1], leader=self)
-        return outs[0], outs[1]
-
-    def _fused_forward(self, input_):
-        """no-grad forward through fq_qlinear_fwd (weight quantized on load); None when not applicable"""
-        w = self.weight
-        if not (3 <= self.w_bits < 32 and w.is_cuda and w.dtype == torch.bfloat16 and input_.dtype == torch.bfloat16 and not self.weight_layerwise):
-            return None
-        ac = ops.autocast_active(w)
-        if ac and not ops.autocast_narrow_ok(w):
-            return None
-        if 2 < self.a_bits < 32:
-            if self.act_quantizer is not SymQuantizer:
-                return None
-            x = _shared_activation(self.act_quantizer, input_, self.a_bits, self.act_layerwise)  # once per sibling group, standalone
-        else:
-            x = input_
-        if x.dtype != torch.bfloat16 or not x.is_contiguous():
-            return None
-        key = (id(w), w._version, w.data_ptr(), self.w_bits, ops.get_semantics(), ac)
-        ent = getattr(self, "_fq_wscales", None)
-        if ent is None or ent[0] != key:  # the row scales change only when the weight does (optimizer step)
-            ent = self._fq_wscales = (key, ops.sym_row_scales(w, self.w_bits, False, autocast=ac))
-        return ops.qlinear_forward(x, w, self.w_bits, self.a_bits, quantize_x=False, quantize_w=True, autocast=ac, w_scales=ent[1])
 
     def export_weight(self, container=None):
         """The integer form of this layer's fake-quantized weight for an inference export: packed bins (int4 for
@@ -926,13 +868,10 @@ class QuantizeLinear(nn.Linear):
         assert len(self.weight.size()) == 2
         if torch.compiler.is_compiling():
             return self._forward_compiled(input_)
-        if _FUSED_QLINEAR and not (torch.is_grad_enabled() and (self.weight.requires_grad or input_.requires_grad)):
-            out = self._fused_forward(input_)
-            if out is not None:
-                return out
         pair = self._pair_forward(input_)
         if pair is not None:
             return nn.functional.linear(pair[1], pair[0])
+        _count("single_launch")
         if self.w_bits >= 32:
             weight = self.weight
         elif self.w_bits >= 3:
@@ -948,6 +887,10 @@ class QuantizeLinear(nn.Linear):
 
 
 try:
+    if _storage_use_count is None:
+        raise RuntimeError("torch._C._storage_Use_Count is not available in this torch build")
     _calibrate_grad_counts()
-except Exception:  # noqa: BLE001 -- without a baseline _inplace_ok() answers False: every gradient takes the copying launch
+except Exception as _e:  # noqa: BLE001 -- without a baseline _inplace_ok() answers False: every gradient takes the copying launch
     _ref_base.clear()
+    _log.warning("llm_qat_amd: the in-place weight-gradient guard could not be calibrated (%r): every weight gradient takes the copying "
+                 "launch (same results; stats() counts them under inplace_refused:uncalibrated)", _e)

@@ -34,7 +34,9 @@ def lib():
         L.fqo_asym_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32]
         L.fqo_ste_bwd.argtypes = [vp, vp, vp, i64, f32, f32, i32]
         L.fqo_w12_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32]
-        L.fqo_sym_fwd_autocast.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32]
+        L.fqo_sym_fwd_autocast.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32]
+        L.fqo_ste_bwd_wide.argtypes = [vp, vp, vp, i64, f32, f32, i32]
+        L.fqo_ste_bwd_wide.restype = ctypes.c_int
         L.fqo_export.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32]
         L.fqo_export.restype = ctypes.c_int
         for f in (L.fqo_sym_fwd, L.fqo_asym_fwd, L.fqo_ste_bwd, L.fqo_w12_fwd, L.fqo_version, L.fqo_sym_fwd_autocast):
@@ -79,15 +81,29 @@ def sym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
     return y, idx, scale
 
 
-def sym_fwd_autocast(x, rows, cols, bits, dtype, wide=True):
-    """SymQuantizer under CUDA autocast on a 16-bit tensor -> (y float32 if wide else dtype bits, idx)."""
+def sym_fwd_autocast(x, rows, cols, bits, dtype, wide=True, sem=SEM_DEVICE, want_scale=False):
+    """SymQuantizer under CUDA autocast on a 16-bit tensor -> (y float32 if wide else dtype bits, idx[, s float32[rows]]).
+    sem: how `max + 1e-6` treats the scalar -- SEM_DEVICE (default: what a real torch.autocast("cuda") run computes) or SEM_CPU
+    (the reference's CPU behaviour; the "cpu" cases of tests/golden/autocast.npz)."""
     x = _check(x, dtype)
     y = np.empty(x.shape, np.float32 if wide else np.uint16)
     idx = np.empty(x.shape, np.int32)
-    rc = lib().fqo_sym_fwd_autocast(_p(x), _p(y), _p(idx), rows, cols, bits, DTYPES[dtype], 1 if wide else 0)
+    scale = np.empty(rows, np.float32)
+    rc = lib().fqo_sym_fwd_autocast(_p(x), _p(y), _p(idx), _p(scale), rows, cols, bits, DTYPES[dtype], 1 if wide else 0, sem)
     if rc:
         raise ValueError(f"fqo_sym_fwd_autocast rc={rc}")
-    return y, idx
+    return (y, idx, scale) if want_scale else (y, idx)
+
+
+def ste_bwd_wide(g32, x, lo, hi, dtype):
+    """STE backward behind the fp32-result forward: fp32 gradient in, gradient in x's (16-bit) dtype out"""
+    g32, x = _check(g32, "fp32"), _check(x, dtype)
+    assert g32.size == x.size
+    gx = np.empty(x.shape, np.uint16)
+    rc = lib().fqo_ste_bwd_wide(_p(g32), _p(x), _p(gx), x.size, lo, hi, DTYPES[dtype])
+    if rc:
+        raise ValueError(f"fqo_ste_bwd_wide rc={rc}")
+    return gx
 
 
 def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
@@ -113,8 +129,11 @@ def asym_fwd(x, rows, cols, bits, dtype, sem=SEM_CPU, want_idx=True):
 CONTAINERS = {"int4": 1, "int8": 2, "int16": 3}
 
 
-def export(kind, x, rows, cols, bits, container, dtype, sem=SEM_CPU, autocast=False):
-    """packed bins (uint8 bytes [rows, row_bytes]), scales float32[rows, 2], overflow int32[rows]"""
+def export(kind, x, rows, cols, bits, container, dtype, sem=None, autocast=False):
+    """packed bins (uint8 bytes [rows, row_bytes]), scales float32[rows, 2], overflow int32[rows].
+    sem=None: SEM_CPU, or SEM_DEVICE with autocast (as sym_fwd_autocast)."""
+    if sem is None:
+        sem = SEM_DEVICE if autocast else SEM_CPU
     x = _check(x, dtype)
     assert x.size == rows * cols
     row_bytes = {"int4": (cols + 1) // 2, "int8": cols, "int16": cols * 2}[container]

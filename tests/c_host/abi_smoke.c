@@ -15,6 +15,7 @@
 
 int fqo_sym_fwd(const void*, void*, int32_t*, float*, int64_t, int64_t, int, int, int);
 int fqo_ste_bwd(const void*, const void*, void*, int64_t, float, float, int);
+int fqo_sym_fwd_autocast(const void* x, void* y, int32_t* idx, float* scale, int64_t rows, int64_t cols, int bits, int dt, int wide, int sem);
 int fqo_export(const void* x, void* bins, float* scales, int32_t* overflow, int64_t rows, int64_t cols, int bits, int container, int dt, int sem,
                int asym, int autocast);
 
@@ -129,41 +130,22 @@ int main(void) {
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(hs, dsc, rows * 8, hipMemcpyDeviceToHost));
         if (memcmp(hs, os, rows * 8)) { fprintf(stderr, "fq_sym_row_scales: mismatch vs the oracle's export scales\n"); return 11; }
-        /* (c) fq_qlinear_fwd: out = fq(x) . fq(W)^T with W = rows 5..36 of the same data (32 out features), x = rows 0..4 (5 tokens),
-         *     in = 11008 (% 64 == 0): the operand tiles as staged for the MFMAs against the oracle, the product against a double sum */
+        /* (c) ABI 4: the autocast arithmetic (fp32 behind the reciprocal; models/utils_quant.py:71-72 under torch.autocast("cuda")) with
+         *     both scalar policies, fp32 result and the result rounded once to bf16 */
         {
-            const int64_t tok = 5, outf = 32;
-            float *dxs, *dws;
-            void *dout, *dumpx, *dumpw;
-            CK(hipMalloc((void**)&dxs, tok * 8)); CK(hipMalloc((void**)&dws, outf * 8)); CK(hipMalloc(&dout, tok * outf * 2));
-            CK(hipMalloc(&dumpx, tok * cols * 2)); CK(hipMalloc(&dumpw, outf * cols * 2));
-            const void* dw = (char*)dx + tok * cols * 2;
-            FQ(fq_sym_row_scales(dx, dxs, tok, cols, 8, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, NULL, NULL, 0, st));
-            FQ(fq_sym_row_scales(dw, dws, outf, cols, 4, FQ_DTYPE_BF16, FQ_SEM_CPU_EAGER, 0, -2.0f, 2.0f, NULL, NULL, 0, st));
-            FQ(fq_qlinear_fwd(dx, dxs, dw, dws, dout, tok, cols, outf, FQ_DTYPE_BF16, 0, dumpx, dumpw, 0, st));
-            CK(hipStreamSynchronize(st));
-            uint16_t *sx = malloc(tok * cols * 2), *sw = malloc(outf * cols * 2), *ho = malloc(tok * outf * 2);
-            CK(hipMemcpy(sx, dumpx, tok * cols * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(sw, dumpw, outf * cols * 2, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(ho, dout, tok * outf * 2, hipMemcpyDeviceToHost));
-            if (fqo_sym_fwd(hx, oy, NULL, NULL, tok, cols, 8, 1, 0) || fqo_sym_fwd(hx + tok * cols, oy + tok * cols, NULL, NULL, outf, cols, 4, 1, 0)) return 4;
-            if (memcmp(sx, oy, tok * cols * 2) || memcmp(sw, oy + tok * cols, outf * cols * 2)) { fprintf(stderr, "fq_qlinear_fwd: staged operands != oracle\n"); return 12; }
-            for (int64_t t = 0; t < tok; ++t)
-                for (int64_t o = 0; o < outf; ++o) {
-                    double acc = 0, mag = 0;
-                    for (int64_t k = 0; k < cols; ++k) {
-                        uint32_t ua = (uint32_t)oy[t * cols + k] << 16, ub = (uint32_t)oy[(tok + o) * cols + k] << 16;
-                        float fa, fb;
-                        memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
-                        acc += (double)fa * fb; mag += (fa < 0 ? -(double)fa : fa) * (fb < 0 ? -(double)fb : fb);
-                    }
-                    uint32_t ur = (uint32_t)ho[t * outf + o] << 16;
-                    float fr;
-                    memcpy(&fr, &ur, 4);
-                    const double tol = (acc < 0 ? -acc : acc) / 256.0 + mag * cols / 16777216.0 + 1e-30;   /* half a bf16 ulp + fp32 accumulation */
-                    if (!(((double)fr - acc < tol) && (acc - (double)fr < tol))) { fprintf(stderr, "fq_qlinear_fwd: out[%lld][%lld] = %g, want %g\n", (long long)t, (long long)o, fr, acc); return 13; }
-                }
+            void* dy32;
+            CK(hipMalloc(&dy32, n * 4));
+            float *hy32 = malloc(n * 4), *oy32 = malloc(n * 4);
+            for (int sem = 0; sem <= 1; ++sem) {
+                FQ(fq_sym_fwd_autocast(dx, dy32, rows, cols, 8, FQ_DTYPE_BF16, sem, 1, -2.0f, 2.0f, NULL, NULL, 0, NULL, 0, st));
+                FQ(fq_sym_fwd_autocast(dx, dy, rows, cols, 4, FQ_DTYPE_BF16, sem, 0, -2.0f, 2.0f, NULL, NULL, 0, NULL, 0, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(hy32, dy32, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy, dy, n * 2, hipMemcpyDeviceToHost));
+                if (fqo_sym_fwd_autocast(hx, oy32, NULL, NULL, rows, cols, 8, 1, 1, sem) || fqo_sym_fwd_autocast(hx, oy, NULL, NULL, rows, cols, 4, 1, 0, sem)) return 4;
+                if (memcmp(hy32, oy32, n * 4) || memcmp(hy, oy, n * 2)) { fprintf(stderr, "autocast arithmetic (sem %d): mismatch vs oracle\n", sem); return 12; }
+            }
         }
     }
-    printf("c host ok: %lld elements x 2 bit widths x 2 data flows, multi-tensor launches, export x 3 containers, row scales and the fused GEMM's operands bit-equal to the oracle\n", (long long)n);
+    printf("c host ok: %lld elements x 2 bit widths x 2 data flows, multi-tensor launches, export x 3 containers, row scales and the autocast arithmetic bit-equal to the oracle\n", (long long)n);
     return 0;
 }

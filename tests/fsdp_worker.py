@@ -2,7 +2,7 @@
 Test infrastructure: started as a fresh child process per rank; both ranks use cuda:0 and a gloo process group (RCCL refuses two
 ranks on one device; FSDP's all-gather / reduce-scatter run over gloo).
 
-    RANK=r WORLD_SIZE=2 MASTER_PORT=p python tests/fsdp_worker.py <eager|ours|ours_groups|ours_wcache> <out.pt>
+    RANK=r WORLD_SIZE=2 MASTER_PORT=p python tests/fsdp_worker.py <eager|ours|ours_wcache> <out.pt>
 
 The reference's real run is `--fsdp "full_shard auto_wrap"` around each decoder layer with gradient checkpointing and bf16 autocast
 (run_train.sh:17-18,:36,:42-43, utils/kd_trainer.py:244): every weight the quantizers see is a view into a flat parameter that is
@@ -32,7 +32,6 @@ def main():
     import llm_qat_amd.utils_quant as UQ
     import tiny_llama as TL
     quant = TL.EagerQuant() if impl == "eager" else UQ
-    llm_qat_amd.group_siblings(impl == "ours_groups")
     llm_qat_amd.enable_weight_quant_cache(impl == "ours_wcache")
     model = TL.load_deterministic(TL.TinyLlama(quant, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
     apply_activation_checkpointing(model, checkpoint_wrapper_fn=functools.partial(checkpoint_wrapper, checkpoint_impl=CheckpointImpl.NO_REENTRANT),

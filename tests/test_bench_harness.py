@@ -129,11 +129,14 @@ HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
 
 
 def _full_record():
-    """a realistic full record: round 2's 27 KB line, plus the round-3 keys"""
+    """a realistic full record: round 2's 27 KB line, re-keyed the way round 4 reports (headline = the step that writes both gradients)"""
     full = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
-    full.update({"value_out_of_place": 755.0, "ms_per_step_out_of_place": 0.1194, "backward_elements_touched": 45088768})
-    full["roofline_step"]["us_per_step_launches"] = 93.0
-    full["roofline_step"]["out_of_place"] = {"bytes_moved_per_step": 732692480, "us_per_step_launches": 119.2, "achieved": 6146.7, "frac": 0.7683}
+    full.update({"value": 744.34, "ms_per_step": 0.1212, "value_product_default": 966.66, "ms_per_step_product_default": 0.0933,
+                 "backward_elements_touched": 2 * 45088768})
+    full["config"]["elements_per_step"] = 2 * 45088768
+    full["roofline_step"].update({"us_per_step_launches": 118.2, "bytes_moved_per_step": 732692480, "achieved": 6198.8, "frac": 0.7748})
+    full["roofline_step"]["product_default"] = {"bytes_moved_per_step": 552337408, "us_per_step_launches": 90.7, "achieved": 6089.7, "frac": 0.7612}
+    full["roofline_step"].pop("out_of_place", None)
     return full
 
 
@@ -143,14 +146,15 @@ def test_headline_is_compact_and_complete():
     line = bench.compact_headline(full, "bench_extras.json")
     assert len(line.encode()) < bench.HEADLINE_MAX_BYTES == 4096
     h = json.loads(line)
-    for k in HEADLINE_KEYS + ("value_out_of_place", "backward_elements_touched"):
+    for k in HEADLINE_KEYS + ("value_product_default", "backward_elements_touched", "self_check"):
         assert k in h, k
     assert len(json.dumps(h["config"])) <= 400 and "model" not in h["config"] and h["config"]["workload"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "kernel"):
         assert k in h["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample", "parity_gate"):
         assert k in h["cpu_baseline"], k
-    assert h["roofline_step"]["frac"] <= 1.0 and h["roofline_step"]["out_of_place"]["frac"] <= 1.0
+    assert h["roofline_step"]["frac"] <= 1.0 and h["roofline_step"]["product_default"]["frac"] <= 1.0
+    assert h["self_check"]["ok"] is True
     assert "hbm_gbs_algorithmic" not in h                      # a GB/s above the 8 TB/s peak has no place in the headline
     assert h["value"] == full["value"] and h["ms_per_step"] == full["ms_per_step"] and h["roofline"]["frac"] == full["roofline"]["frac"]
 
@@ -185,3 +189,61 @@ def test_stub_line_is_compact_too():
     assert p.returncode == 0
     last = p.stdout.strip().splitlines()[-1]
     assert len(last.encode()) < 4096 and json.loads(last)["data"] == "stub"
+
+
+# ---- the cross-checks a reader can redo from the line alone --------------------------------------------
+def test_self_check_flags_round_3s_headline_and_passes_the_like_for_like_one():
+    """BENCH_r03.json: value 966.66 Gelem/s at 0.0933 ms/step is 10 B x 90.2 M elements / 93.3 us = 9.67 TB/s under SURVEY §8d's
+    accounting -- above the 8 TB/s peak (the timed step's W4 backward moved nothing); and its separately timed launches summed to
+    101.81 us, more than the 93.3 us step that contains them (20 launches after 4 warm-ups).  Both must be flagged."""
+    elems = 2 * 45088768
+    r03 = {"ms_per_step": 0.0933, "value": 966.66, "n_gpus": 1, "config": {"elements_per_step": elems},
+           "roofline": {"frac": 0.7443}, "roofline_step": {"frac": 0.678, "us_per_step_launches": 101.81}}
+    sc = bench.self_check(r03)
+    assert sc["ok"] is False and sc["accounting_below_peak"] is False and sc["launch_sum_within_step"] is False
+    assert 9600 < sc["accounting_gbs_10B_per_elem"] < 9700
+    good = {"ms_per_step": 0.1212, "value": 744.34, "n_gpus": 1, "config": {"elements_per_step": elems},
+            "roofline": {"frac": 0.757}, "roofline_step": {"frac": 0.775, "us_per_step_launches": 118.2}}
+    sc = bench.self_check(good)
+    assert sc["ok"] is True and sc["accounting_gbs_10B_per_elem"] <= bench.HBM_PEAK_GBS and sc["launch_sum_vs_step"] <= 1.03
+    assert bench.self_check({"stub": True, "ms_per_step": 1.0}) is None
+
+
+def test_kernel_timing_protocol_is_independent_of_steps():
+    """every per-kernel entry: >= 200 launches after >= 20 warm-ups whatever --steps says; us_per_launch = p50 of bracketed launches"""
+    class _Ev:
+        clock = [0.0]
+
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = _Ev.clock[0]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    class _Cuda:
+        Event = _Ev
+
+        @staticmethod
+        def synchronize():
+            pass
+
+    class _Torch:
+        cuda = _Cuda
+
+    calls = []
+
+    def fn(s):
+        calls.append(s)
+        _Ev.clock[0] += 0.05 if len(calls) % 10 else 0.5     # every tenth launch is an outlier: the p50 ignores it, the mean does not
+
+    del bench.PROFILE_MANIFEST[:]
+    t = bench.time_launches(_Torch, fn, 20, [0, 1, 2, 3], name="k")        # the driver's --steps 20
+    assert t.iters >= 200 and t.warmup >= 20 and len(calls) == t.warmup + 2 * t.iters
+    ms, pct = t
+    assert abs(ms - 0.05) < 1e-9 and pct[1] == ms and t.mean_back_to_back > ms
+    assert bench.PROFILE_MANIFEST[-1] == ("k", t.warmup + 2 * t.iters)
+    e = bench.roofline_entry("k", 1000, t)
+    assert e["launches_timed"] >= 200 and e["warmup_launches"] >= 20 and e["us_per_launch"] == 50.0

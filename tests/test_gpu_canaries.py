@@ -74,10 +74,10 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
             if es == 2:   # the autocast arithmetic: bf16/fp16 in, fp32 (wide) or same-dtype (narrow) out
                 y32 = Guarded(n * 4, off * 2)
                 everything.append(y32)
-                ok(L.fq_sym_fwd_autocast(x.ptr, y32.ptr, rows, cols, 8, code, 1, -2.0, 2.0, bounds.ptr, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast wide")
-                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, bounds.ptr, mask.ptr if mb else None, mb, ws.ptr, wsb, st),
+                ok(L.fq_sym_fwd_autocast(x.ptr, y32.ptr, rows, cols, 8, code, 1, 1, -2.0, 2.0, bounds.ptr, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast wide")
+                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 1, 0, -2.0, 2.0, bounds.ptr, mask.ptr if mb else None, mb, ws.ptr, wsb, st),
                    "sym_fwd_autocast narrow", allow=(-8,))
-                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 0, -2.0, 2.0, None, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast narrow plain")
+                ok(L.fq_sym_fwd_autocast(x.ptr, y.ptr, rows, cols, 4, code, 1, 0, -2.0, 2.0, None, None, 0, ws.ptr, wsb, st), "sym_fwd_autocast narrow plain")
             if mb:   # two tensors per launch (second tensor: its own guarded buffers, rows2 rows), every flavour
                 rows2 = max(1, rows // 2)
                 n2 = rows2 * cols
@@ -108,7 +108,7 @@ def test_no_entry_point_writes_outside_its_buffers(dtype, code, es):
                     if rc == 0:
                         ok(L.fq_ste_bwd_mask_wide(g32.ptr, gx.ptr, rows, bounds.ptr, mask.ptr, g32b.ptr, gx2.ptr, rows2, b2.ptr, m2.ptr,
                                                   cols, -2.0, 2.0, code, st), "ste_bwd_mask_wide pair", allow=(-8,))
-                    rc = L.fq_sym_fwd_autocast(x.ptr, yw.ptr, rows, cols, 8, code, 1, -2.0, 2.0, bounds.ptr, mask.ptr, mb, ws.ptr, wsb, st)
+                    rc = L.fq_sym_fwd_autocast(x.ptr, yw.ptr, rows, cols, 8, code, 1, 1, -2.0, 2.0, bounds.ptr, mask.ptr, mb, ws.ptr, wsb, st)
                     ok(rc, "sym_fwd_autocast wide + mask", allow=(-8,))
                     if rc == 0:
                         ok(L.fq_ste_bwd_mask_wide(g32.ptr, gx.ptr, rows, bounds.ptr, mask.ptr, None, None, 0, None, None, cols, -2.0, 2.0, code, st),
@@ -188,8 +188,13 @@ def test_round2_entry_points_stay_inside_their_buffers(dtype, code, es):
 
 
 def test_qlinear_stays_inside_its_buffers():
+    """the fused-GEMM experiment (tools/qlinear, not part of the product library) stays inside its buffers too"""
+    import os
+    import sys
     from llm_qat_amd import _lib
-    L = _lib.lib()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "qlinear"))
+    import qlinear as QX
+    L, LQ = _lib.lib(), QX.lib()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(5)
     for m, n, k in [(1, 4, 64), (300, 388, 192), (257, 132, 128), (512, 256, 64)]:
@@ -201,9 +206,9 @@ def test_qlinear_stays_inside_its_buffers():
         assert L.fq_sym_row_scales(x.ptr, xs.ptr, m, k, 8, 1, 0, 0, -2.0, 2.0, None, None, 0, st) == 0
         assert L.fq_sym_row_scales(w.ptr, ws.ptr, n, k, 4, 1, 0, 0, -2.0, 2.0, None, None, 0, st) == 0
         for qa, qw, ac, dump, abl in [(1, 1, 0, 1, 0), (0, 1, 0, 0, 0), (1, 0, 1, 0, 0), (0, 0, 0, 0, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1), (1, 1, 0, 0, 2)]:
-            rc = L.fq_qlinear_fwd(x.ptr, xs.ptr if qa else None, w.ptr, ws.ptr if qw else None, out.ptr, m, k, n, 1, ac,
-                                  dx.ptr if dump else None, dw.ptr if dump else None, abl, st)
-            assert rc == 0, L.fq_last_error()
+            rc = LQ.fq_qlinear_fwd(x.ptr, xs.ptr if qa else None, w.ptr, ws.ptr if qw else None, out.ptr, m, k, n, 1, ac,
+                                   dx.ptr if dump else None, dw.ptr if dump else None, abl, st)
+            assert rc == 0, LQ.fq_qlinear_last_error()
             torch.cuda.synchronize()
             for b in every:
                 assert b.intact(), f"qlinear [{m},{k}]x[{n},{k}] qa={qa} qw={qw} ac={ac} dump={dump} abl={abl}: canary overwritten"

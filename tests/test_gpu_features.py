@@ -614,6 +614,7 @@ def test_unchanged_kv_call_site_is_one_launch(pkg, autocast):
     def run(pairing, variant="reference"):
         pkg.pair_kv_hooks(pairing)
         pkg.pair_operands(True)
+        pkg.reset_learned_state()   # (a wrong guess switches the speculation off for that call signature: see the next test)
         try:
             for m in (kp, vp):
                 m.weight.grad = None
@@ -639,6 +640,7 @@ def test_unchanged_kv_call_site_is_one_launch(pkg, autocast):
     counts = {}
     for pairing in (True, False):
         pkg.pair_kv_hooks(pairing)
+        pkg.reset_learned_state()
         try:
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 with Counter(pkg.ops, names + ["sym_quantize"]) as c:
@@ -648,6 +650,70 @@ def test_unchanged_kv_call_site_is_one_launch(pkg, autocast):
         counts[pairing] = c.n
         assert torch.equal(k, run(False)[0]) and torch.equal(v, run(False)[1])
     assert counts[True] == counts[False] - 1, counts
+
+
+def test_kv_speculation_stops_after_a_wrong_guess_and_says_so(pkg):
+    """a call site that quantizes K only (or V with other bits) must not pay for a speculative V forever -- after ONE
+    discarded result that call signature stops pairing, the pending result (graph + side buffers) is dropped when the next backward
+    starts, and llm_qat_amd.stats() shows all of it."""
+    from llm_qat_amd import utils_quant as U
+    from llm_qat_amd.utils_quant import QuantizeLinear, SymQuantizer
+    torch.manual_seed(4)
+    clip = torch.tensor([-2.0, 2.0])
+    kp, vp = (QuantizeLinear(256, 256, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(2))
+    h = (torch.randn(2, 16, 256, device="cuda") * 1.1).bfloat16().requires_grad_(True)
+    pkg.reset_learned_state()
+    pkg.stats(reset=True)
+
+    def k_only_step():
+        k, v = kp(h), vp(h)
+        k = SymQuantizer.apply(k, clip, 4, False)       # the V hook never comes
+        (k.float().square().mean() + v.float().square().mean()).backward()
+
+    with Counter(pkg.ops, ["pair_forward"]) as c:
+        k_only_step()
+    st = pkg.stats()
+    assert st.get("kv_pair_launch") == 1 and st.get("kv_pair_discarded") == 1 and st.get("kv_pair_learned_off") == 1 and not st.get("kv_pair_hit"), st
+    assert getattr(U._tls, "kv_stash", None) is None, "the unused V result stayed pinned after the backward"
+    n_first = c.n
+    with Counter(pkg.ops, ["pair_forward"]) as c:
+        k_only_step()
+        k_only_step()
+    assert c.n == 2 * (n_first - 1), "the site kept speculating after a wrong guess"
+    assert pkg.stats().get("kv_pair_launch") == 1
+    # the ordinary two-hook site with ANOTHER signature still pairs; after reset_learned_state() so does this one
+    pkg.reset_learned_state()
+    k, v = kp(h), vp(h)
+    k, v = SymQuantizer.apply(k, clip, 4, False), SymQuantizer.apply(v, clip, 4, False)
+    st = pkg.stats()
+    assert st.get("kv_pair_launch") == 2 and st.get("kv_pair_hit") == 1, st
+    (k.float().mean() + v.float().mean()).backward()
+
+
+def test_forward_under_inference_mode(pkg):
+    """inference tensors have no version counter (`t._version` raises); the bookkeeping of activation sharing,
+    operand pairing and the K/V hooks must step aside -- the reference works under torch.inference_mode(), so does the drop-in,
+    with the values of the no_grad forward."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    ids = TL.deterministic_batch().cuda()
+    for dt, kv in ((torch.bfloat16, 4), (torch.float32, 8)):
+        m = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=kv).to(dt)).cuda()
+        with torch.no_grad():
+            want = m(ids)[1]
+        with torch.inference_mode():
+            got = m(ids)[1]
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                got_ac = m(ids)[1]
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            want_ac = m(ids)[1]
+        assert torch.equal(got, want) and torch.equal(got_ac, want_ac), dt
+        # a model BUILT under inference mode (its parameters are inference tensors) too
+        with torch.inference_mode():
+            mi = TL.load_deterministic(TL.TinyLlama(UQ, w_bits=4, a_bits=8, kv_bits=kv).to(dt)).cuda()
+            assert torch.equal(mi(ids)[1], want), dt
 
 
 def _one_rank_group():
@@ -723,7 +789,7 @@ def test_two_rank_fsdp_full_shard_with_checkpointing(pkg, tmp_path):
     import subprocess
     import sys
     res = {}
-    for impl in ("eager", "ours", "ours_wcache", "ours_groups"):
+    for impl in ("eager", "ours", "ours_wcache"):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -738,7 +804,7 @@ def test_two_rank_fsdp_full_shard_with_checkpointing(pkg, tmp_path):
         res[impl] = torch.load(out, weights_only=True)
     ref = res["eager"]
     assert torch.isfinite(ref["losses"]).all() and ref["losses"][0] != ref["losses"][2]
-    for impl in ("ours", "ours_wcache", "ours_groups"):
+    for impl in ("ours", "ours_wcache"):
         got = res[impl]
         assert torch.equal(got["losses"], ref["losses"]), (impl, got["losses"], ref["losses"])
         assert set(got["params"]) == set(ref["params"])
@@ -1085,6 +1151,27 @@ def test_inplace_weight_gradient_is_guarded(pkg):
     with torch.autograd.detect_anomaly(check_nan=False):
         assert not U._inplace_ok(g)
     assert U._inplace_ok(g)
+    # an alias made WITHOUT view tracking (its own TensorImpl, no _base) shares the storage: the storage's own holder
+    # count shows it
+    alias = g.data
+    pkg.stats(reset=True)
+    assert not U._inplace_ok(g) and pkg.stats().get("inplace_refused:storage_refs") == 1, pkg.stats()
+    del alias
+    assert U._inplace_ok(g)
+    # the guarded path engages for EVERY weight node, not only the pair node: _SymQuantizerWeight (operands quantized separately)
+    # and _ReuseQuantizedWeight (weight cache), and llm_qat_amd.stats() counts it
+    for setup, teardown in (((lambda: pkg.pair_operands(False)), (lambda: pkg.pair_operands(True))),
+                            ((lambda: pkg.enable_weight_quant_cache(True)), (lambda: pkg.enable_weight_quant_cache(False)))):
+        setup()
+        try:
+            pkg.stats(reset=True)
+            lin.weight.grad = x.grad = None
+            lin(x).float().square().sum().backward()
+            st = pkg.stats()
+            assert st.get("inplace_taken") == 1 and not any(k.startswith("inplace_refused") for k in st), st
+            assert torch.equal(lin.weight.grad, want_w) and torch.equal(x.grad, want_x)
+        finally:
+            teardown()
 
 
 # ------------------------------------------------------------------------------------------ N-tensor launches
@@ -1119,57 +1206,6 @@ def test_multi_tensor_launch_matches_separate_calls(pkg, dtype):
     # not served: different row lengths / dtypes / too many tensors -> None (the caller falls back to separate calls)
     assert ops.multi_forward([tensors[0], tensors[0][:, :512].contiguous()], [4, 4], [False, False], -2.0, 2.0) is None
     assert ops.multi_forward(tensors + [tensors[0]], bits + [4], [False] * 5, -2.0, 2.0) is None
-
-
-@pytest.mark.parametrize("autocast", [False, True])
-def test_sibling_projections_share_one_launch(pkg, autocast):
-    """q/k/v-style siblings: from the second forward on the leader quantizes its weight, the shared input and both
-    siblings' weights in ONE launch and one backward launch returns the four gradients -- bit-identical to the ungrouped
-    flow across training steps (weights change between steps), in eval, and when a sibling's weight changes between the
-    leader's launch and its own forward."""
-    from llm_qat_amd.utils_quant import QuantizeLinear
-    torch.manual_seed(0)
-    names = ["multi_forward", "multi_backward", "pair_forward", "pair_backward", "train_forward", "train_backward", "sym_forward_autocast"]
-
-    def run(group):
-        torch.manual_seed(1)
-        mods = [QuantizeLinear(1024, 768, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(3)]
-        opt = torch.optim.SGD([m.weight for m in mods], lr=0.05)
-        pkg.group_siblings(group)
-        log = []
-        try:
-            for step in range(3):
-                x = (torch.randn(2, 64, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + step)) * 1.5).bfloat16().requires_grad_(True)
-                opt.zero_grad(set_to_none=True)
-                with Counter(pkg.ops, names) as c:
-                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-                        loss = qkv_loss(mods, x)
-                    loss.backward()
-                log.append((loss.detach().clone(), x.grad.clone(), [m.weight.grad.clone() for m in mods], c.n))
-                opt.step()
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-                xe = (torch.randn(2, 64, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(99)) * 1.5).bfloat16()
-                ev = [m(xe) for m in mods]
-                # a sibling's weight changes after the leader prefetched it: the stale prefetch must not be used
-                o0 = mods[0](xe)
-                mods[1].weight.mul_(2.0)
-                o1 = mods[1](xe)
-            log.append((ev, o0, o1))
-        finally:
-            pkg.group_siblings(False)   # the default
-        return log
-
-    a, b = run(True), run(False)
-    for s in range(3):
-        assert torch.equal(a[s][0], b[s][0]) and torch.equal(a[s][1], b[s][1]), f"step {s}"
-        for ga, gb in zip(a[s][2], b[s][2]):
-            assert torch.equal(ga, gb), f"step {s}"
-    for ea, eb in zip(a[3][0], b[3][0]):
-        assert torch.equal(ea, eb)
-    assert torch.equal(a[3][1], b[3][1]) and torch.equal(a[3][2], b[3][2])
-    # launches per step: ungrouped 1 pair + 2 weights forward, the same backward = 6; grouped (from step 1 on) 1 + 1
-    assert b[0][3] == 6 and b[2][3] == 6, (b[0][3], b[2][3])
-    assert a[0][3] == 6 and a[1][3] == 2 and a[2][3] == 2, (a[0][3], a[1][3], a[2][3])
 
 
 # ------------------------------------------------------------------------------------------ weight gradients by reference

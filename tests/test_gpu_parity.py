@@ -703,7 +703,7 @@ def test_wide_result_mask_path_vs_oracle(ops, dtype):
             # single tensor: fq_sym_fwd_autocast(wide_out=1, mask) -> fq_ste_bwd_mask_wide(rows1 = 0)
             y = torch.empty(r0, cols, device="cuda")
             s0, mb0 = side(r0, cols)
-            rc = L.fq_sym_fwd_autocast(x0.data_ptr(), y.data_ptr(), r0, cols, bits, code, 1, lo, hi, s0.data_ptr(), s0.data_ptr() + r0 * 8, mb0, None, 0, st)
+            rc = L.fq_sym_fwd_autocast(x0.data_ptr(), y.data_ptr(), r0, cols, bits, code, 1, 1, lo, hi, s0.data_ptr(), s0.data_ptr() + r0 * 8, mb0, None, 0, st)
             _lib.check(rc, "wide fwd")
             yo, _ = O.sym_fwd_autocast(x0_np, r0, cols, bits, dtype, wide=True)
             assert bits_equal(np_from(y).reshape(yo.shape), yo, "fp32"), f"{dtype} cols={cols} wide fwd"
@@ -719,7 +719,7 @@ def test_wide_result_mask_path_vs_oracle(ops, dtype):
             s1, mb1 = side(r1, cols)
             rc = L.fq_sym_fwd_pair(x0.data_ptr(), y0.data_ptr(), r0, bits, s0.data_ptr(), s0.data_ptr() + r0 * 8, mb0,
                                    x1.data_ptr(), y1.data_ptr(), r1, bits, s1.data_ptr(), s1.data_ptr() + r1 * 8, mb1,
-                                   cols, code, 0, 2, lo, hi, st)
+                                   cols, code, 1, 2, lo, hi, st)
             _lib.check(rc, "wide pair fwd")
             yo1, _ = O.sym_fwd_autocast(x1_np, r1, cols, bits, dtype, wide=True)
             assert bits_equal(np_from(y0).reshape(yo.shape), yo, "fp32") and bits_equal(np_from(y1).reshape(yo1.shape), yo1, "fp32"), f"{dtype} cols={cols} pair fwd"
@@ -734,7 +734,7 @@ def test_wide_result_mask_path_vs_oracle(ops, dtype):
     x = torch.randn(2, 40000, device="cuda").to(TD[dtype])
     y = torch.empty(2, 40000, device="cuda")
     s, mb = side(2, 40000)
-    rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), 2, 40000, 8, code, 1, -2.0, 2.0, s.data_ptr(), s.data_ptr() + 16, mb, None, 0, st)
+    rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), 2, 40000, 8, code, 1, 1, -2.0, 2.0, s.data_ptr(), s.data_ptr() + 16, mb, None, 0, st)
     assert rc == _lib.ERR_UNSUPPORTED
 
 
@@ -803,7 +803,7 @@ def test_ste_mask_is_the_documented_row_bitmap(ops, dtype):
             for wide in (0, 1):
                 side = torch.zeros(rows * 8 + mb, dtype=torch.uint8, device="cuda")
                 y = torch.empty(rows, cols, device="cuda", dtype=torch.float32 if wide else TD[dtype])
-                rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), rows, cols, 8, code, wide, lo, hi, side.data_ptr(), side.data_ptr() + rows * 8, mb, None, 0, st)
+                rc = L.fq_sym_fwd_autocast(x.data_ptr(), y.data_ptr(), rows, cols, 8, code, 1, wide, lo, hi, side.data_ptr(), side.data_ptr() + rows * 8, mb, None, 0, st)
                 _lib.check(rc, "autocast fwd")
                 check(side, rows, cols, x_np, lo, hi, f"fq_sym_fwd_autocast wide={wide} {dtype} {(rows, cols)} clip=({lo},{hi})")
                 sides[wide] = side

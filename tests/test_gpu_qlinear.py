@@ -1,16 +1,23 @@
-"""GPU tier: SURVEY §8 f4a -- fq_qlinear_fwd, QuantizeLinear's no-grad forward with the fake-quant fused into the GEMM's
-operand loads.
+"""GPU tier: SURVEY §8 f4a -- the quantize-on-load GEMM EXPERIMENT under tools/qlinear/ (not part of the product library since
+round 4: measured slower than the unfused product path): QuantizeLinear's no-grad forward with the fake-quant
+fused into the GEMM's operand loads.
   * the MFMA path itself on exact integer data (asymmetric operands, tails in every dimension): bit-exact vs fp32 matmul
   * the operand tiles as staged for the MFMAs, dumped: bit-identical to fq_sym_fwd / fq_sym_fwd_autocast(narrow)
   * the product: within the stated fp32-accumulation tolerance of the exact product of those operands, and of
     F.linear(fq(x), fq(W)) as the unfused path computes it
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 from oracle import oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "qlinear"))
+import qlinear as QX  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +58,7 @@ def test_mfma_path_exact_on_integer_data(ops, shape):
     w = torch.randint(-2, 3, (n, k), generator=g, device="cuda").to(torch.bfloat16)
     w[:, 0] = 1
     x[0, :] = 2      # asymmetric: a row of x and a column of W stand out
-    out = ops.qlinear_forward(x, w, 8, 8, quantize_x=False, quantize_w=False, autocast=False)
+    out = QX.qlinear_forward(x, w, 8, 8, quantize_x=False, quantize_w=False, autocast=False)
     assert out is not None and out.shape == (m, n)
     want = (x.float() @ w.float().t())
     assert want.abs().max() <= 256 * 16
@@ -67,7 +74,7 @@ def test_staged_tiles_are_bit_identical_to_the_quantizer(ops, shape, autocast):
     x[torch.rand(m, k, generator=g, device="cuda") < 1e-3] *= 20
     x = x.to(torch.bfloat16)
     w = (torch.randn(n, k, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
-    out, sx, sw = ops.qlinear_forward(x, w, 4, 8, autocast=autocast, dump=True)
+    out, sx, sw = QX.qlinear_forward(x, w, 4, 8, autocast=autocast, dump=True)
     if autocast:
         xq = ops.sym_forward_autocast(x, 8, False, wide=False)[0]
         wq = ops.sym_forward_autocast(w, 4, False, wide=False)[0]
@@ -89,7 +96,7 @@ def test_staged_tiles_are_bit_identical_to_the_quantizer(ops, shape, autocast):
     unf = F.linear(xq, wq)
     assert ((out.double() - unf.double()).abs() <= ref.abs() * 2.0 ** -7 + mag * k * 2.0 ** -23 + 1e-30).all()
     # mixed: only W quantized on load, x handed over already quantized == both on load, bit for bit (same staged values)
-    out2 = ops.qlinear_forward(xq, w, 4, 8, quantize_x=False, autocast=autocast)
+    out2 = QX.qlinear_forward(xq, w, 4, 8, quantize_x=False, autocast=autocast)
     assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
 
 
@@ -98,7 +105,7 @@ def test_llama7b_shape_full_size(ops):
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(2048, 11008, generator=g, device="cuda").to(torch.bfloat16)
     w = (torch.randn(4096, 11008, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
-    out, sx, sw = ops.qlinear_forward(x, w, 4, 8, autocast=False, dump=True)
+    out, sx, sw = QX.qlinear_forward(x, w, 4, 8, autocast=False, dump=True)
     xq, wq = ops.sym_quantize(x, 8), ops.sym_quantize(w, 4)
     assert torch.equal(sx.view(torch.int16), xq.view(torch.int16)) and torch.equal(sw.view(torch.int16), wq.view(torch.int16))
     # sampled rows of both staged operands against the oracle (incl. the first / last row of every 256- / 128-row tile edge)
@@ -106,7 +113,7 @@ def test_llama7b_shape_full_size(ops):
     rw = torch.unique(torch.cat([torch.arange(0, 4096, 97), torch.tensor([0, 127, 128, 4095])])).cuda()
     assert (bits(sx[rx]) == oracle_operand(x, 8, False, rx)).all(), "staged x rows != oracle"
     assert (bits(sw[rw]) == oracle_operand(w, 4, False, rw)).all(), "staged W rows != oracle"
-    out_ac, sx_ac, sw_ac = ops.qlinear_forward(x, w, 4, 8, autocast=True, dump=True)
+    out_ac, sx_ac, sw_ac = QX.qlinear_forward(x, w, 4, 8, autocast=True, dump=True)
     assert (bits(sx_ac[rx]) == oracle_operand(x, 8, True, rx)).all() and (bits(sw_ac[rw]) == oracle_operand(w, 4, True, rw)).all(), "autocast staging != oracle"
     unf = F.linear(xq, wq).float()
     err = (out.float() - unf).abs()
@@ -117,49 +124,5 @@ def test_llama7b_shape_full_size(ops):
 def test_unserved_shapes_return_none(ops):
     x = torch.randn(8, 100, device="cuda").to(torch.bfloat16)
     w = torch.randn(16, 100, device="cuda").to(torch.bfloat16)
-    assert ops.qlinear_forward(x, w, 4, 8) is None                       # in_features % 64 != 0
-    assert ops.qlinear_forward(x.float(), w.float(), 4, 8) is None       # bf16 only
-
-
-@pytest.mark.parametrize("autocast", [False, True])
-def test_module_opt_in_fused_forward(ops, autocast):
-    """QuantizeLinear with fuse_qlinear(True): eval / no-grad forwards take fq_qlinear_fwd (weight quantized on load, the
-    activation quantized once and shared by siblings); training forwards are untouched.  Same operand values, product
-    within a bf16 ulp of the default path's."""
-    import llm_qat_amd
-    from llm_qat_amd.utils_quant import QuantizeLinear
-    torch.manual_seed(4)
-    q, k = (QuantizeLinear(1024, 512, w_bits=4, a_bits=8).cuda().bfloat16() for _ in range(2))
-    x = torch.randn(3, 100, 1024, device="cuda").bfloat16()
-    calls = []
-    orig = llm_qat_amd.ops.qlinear_forward
-
-    def spy(*a, **kw):
-        calls.append(1)
-        return orig(*a, **kw)
-
-    llm_qat_amd.ops.qlinear_forward = spy
-    try:
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            ref = [m(x) for m in (q, k)]
-            llm_qat_amd.fuse_qlinear(True)
-            got = [m(x) for m in (q, k)]
-            assert len(calls) == 2
-            for a, b in zip(got, ref):
-                assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape
-                assert ((a.float() - b.float()).abs() <= b.float().abs() * 2.0 ** -7 + 1e-3).all()
-        # a training forward never takes the fused path
-        xg = x.clone().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            q(xg).float().sum().backward()
-        assert len(calls) == 2 and xg.grad is not None and q.weight.grad is not None
-        # weight update -> the cached row scales are recomputed
-        with torch.no_grad():
-            q.weight.mul_(1.5)
-            a = q(x)
-            llm_qat_amd.fuse_qlinear(False)
-            b = q(x)
-        assert ((a.float() - b.float()).abs() <= b.float().abs() * 2.0 ** -7 + 1e-3).all()
-    finally:
-        llm_qat_amd.ops.qlinear_forward = orig
-        llm_qat_amd.fuse_qlinear(False)
+    assert QX.qlinear_forward(x, w, 4, 8) is None                       # in_features % 64 != 0
+    assert QX.qlinear_forward(x.float(), w.float(), 4, 8) is None       # bf16 only

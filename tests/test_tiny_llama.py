@@ -166,14 +166,12 @@ def test_dropin_with_kv_hooks_in_one_launch(autocast):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grouping", [False, True])
 @pytest.mark.parametrize("reentrant", [True, False])
-def test_training_steps_with_sibling_grouping_match_eager_chain(reentrant, grouping):
+def test_training_steps_match_eager_chain(reentrant):
     """Several optimizer steps of run_train.sh's combination (bf16 autocast + per-layer activation checkpointing): every
-    step's loss and every parameter after every step stay bit-identical to the eager chain.  grouping=True (opt-in since
-    round 3: it bought nothing end to end): from the second step on q/k/v and gate/up sibling groups are served with ONE
-    launch each (learned in step one, active once the weights have changed) -- and a checkpointed forward and its recompute
-    always build the same graph.  grouping=False (the default): no multi-tensor launch ever happens."""
+    step's loss and every parameter after every step stay bit-identical to the eager chain -- a checkpointed forward and its
+    recompute always build the same graph.  (The learned sibling-group dispatch of rounds 2-3 is gone: no multi-tensor launch
+    ever happens at module level.)"""
     from torch.utils.checkpoint import checkpoint
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
@@ -201,15 +199,12 @@ def test_training_steps_with_sibling_grouping_match_eager_chain(reentrant, group
     calls = []
     orig = llm_qat_amd.ops.multi_forward
     llm_qat_amd.ops.multi_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    assert UQ._GROUP is False, "sibling groups are opt-in"
-    llm_qat_amd.group_siblings(grouping)
     try:
         l_ref, p_ref = train(ref)
         l, p = train(ours)
     finally:
         llm_qat_amd.ops.multi_forward = orig
-        llm_qat_amd.group_siblings(False)
-    assert (len(calls) > 0) == grouping, "the sibling groups never became active" if grouping else "sibling groups ran although they are off by default"
+    assert not calls
     for s, (a, b) in enumerate(zip(l, l_ref)):
         assert torch.equal(a, b), (s, a.item(), b.item())
     for a, b, (n, _) in zip(p, p_ref, ours.named_parameters()):

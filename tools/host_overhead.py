@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """Host-side cost per quantizer call (Python + ctypes + allocator + autograd), measured on a tensor small enough
-that the GPU is never the bottleneck.   python tools/host_overhead.py"""
-import os, sys, time
+that the GPU is never the bottleneck, with a breakdown of where the microseconds go.   python tools/host_overhead.py"""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-import llm_qat_amd
-from llm_qat_amd.utils_quant import SymQuantizer
+import torch  # noqa: E402
+
+import llm_qat_amd  # noqa: E402
+from llm_qat_amd import _lib, ops  # noqa: E402
+from llm_qat_amd.utils_quant import QuantizeLinear, SymQuantizer  # noqa: E402
+
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from tiny_llama import EagerQuant   # test infrastructure: the reference's eager op chain as autograd Functions
+from tiny_llama import EagerQuant   # noqa: E402  test infrastructure: the reference's eager op chain as autograd Functions
+
 EagerSym = EagerQuant().SymQuantizer
 
 clip = torch.tensor([-2.0, 2.0])
@@ -16,23 +24,58 @@ x = torch.randn(64, 256, device="cuda", dtype=torch.bfloat16)
 xg = x.clone().requires_grad_(True)
 g = torch.ones_like(x)
 N = 2000
-from llm_qat_amd import ops
-res = ops.train_forward("sym", x, 8, False, -2.0, 2.0)
-_, side, rows, cols = res
+_, side, rows, cols = ops.train_forward("sym", x, 8, False, -2.0, 2.0)
 outs = [SymQuantizer.apply(xg, clip, 8, False) for _ in range(64)]
+L = _lib.lib()
+st = torch.cuda.current_stream().cuda_stream
+y = torch.empty_like(x)
+mb = L.fq_ste_mask_bytes(rows, cols, _lib.DTYPE_BF16)
+xp, yp, sp = x.data_ptr(), y.data_ptr(), side.data_ptr()
+lin = QuantizeLinear(256, 256, w_bits=4, a_bits=8).cuda().bfloat16()
+xl = torch.randn(64, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+gl = torch.ones(64, 256, device="cuda", dtype=torch.bfloat16)
+
+
+class _Noop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c, d):
+        ctx.save_for_backward(b)
+        return a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, go):
+        return go, None, None, None
 
 
 def many_backward():
     torch.autograd.backward(outs, [g] * 64, retain_graph=True)
 
-for name, fn in (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, clip, 8, False)),
-                 ("llm_qat_amd fwd (grad)", lambda: SymQuantizer.apply(xg, clip, 8, False)),
-                 ("llm_qat_amd fwd+bwd", lambda: SymQuantizer.apply(xg, clip, 8, False).backward(g)),
-                 ("ops.train_forward only", lambda: ops.train_forward("sym", x, 8, False, -2.0, 2.0)),
-                 ("ops.train_backward only", lambda: ops.train_backward(g, side, rows, cols, -2.0, 2.0)),
-                 ("autograd.backward over 64 nodes (/64)", many_backward),
-                 ("eager chain fwd (grad)", lambda: EagerSym.apply(xg, clip, 8, False)),
-                 ("eager chain fwd+bwd", lambda: EagerSym.apply(xg, clip, 8, False).backward(g))):
+
+def raw_launch():
+    L.fq_sym_fwd_train(xp, yp, rows, cols, 8, _lib.DTYPE_BF16, 0, -2.0, 2.0, sp, sp + rows * 8, mb, st)
+
+
+def module_step():
+    lin.weight.grad = xl.grad = None
+    lin(xl).backward(gl)
+
+
+CASES = (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, clip, 8, False)),
+         ("llm_qat_amd fwd (grad)", lambda: SymQuantizer.apply(xg, clip, 8, False)),
+         ("llm_qat_amd fwd+bwd", lambda: SymQuantizer.apply(xg, clip, 8, False).backward(g)),
+         ("ops.train_forward only", lambda: ops.train_forward("sym", x, 8, False, -2.0, 2.0)),
+         ("ops.train_backward only", lambda: ops.train_backward(g, side, rows, cols, -2.0, 2.0)),
+         ("autograd.backward over 64 nodes (/64)", many_backward),
+         ("  part: raw C-ABI launch, preallocated buffers", raw_launch),
+         ("  part: torch.empty_like + torch.empty(side)", lambda: (torch.empty_like(x), torch.empty(rows * 8 + mb, dtype=torch.uint8, device=x.device))),
+         ("  part: autograd.Function.apply of a no-op (grad)", lambda: _Noop.apply(xg, clip, 8, False)),
+         ("  part: autograd.Function.apply of a no-op (no grad)", lambda: _Noop.apply(x, clip, 8, False)),
+         ("  part: torch._C._cuda_getCurrentRawStream", lambda: ops._stream(x)),
+         ("QuantizeLinear(256->256) fwd+bwd incl. F.linear", module_step),
+         ("eager chain fwd (grad)", lambda: EagerSym.apply(xg, clip, 8, False)),
+         ("eager chain fwd+bwd", lambda: EagerSym.apply(xg, clip, 8, False).backward(g)))
+res = {}
+for name, fn in CASES:
     best = float("inf")
     for rep in range(3):   # best of three: the first loop of a process runs ~2x slow (measured), whatever it times
         for _ in range(50):
@@ -45,4 +88,8 @@ for name, fn in (("llm_qat_amd fwd (no grad)", lambda: SymQuantizer.apply(x, cli
         torch.cuda.synchronize()
         best = min(best, t1 - t0)
     per = 1e6 * best / N / (64 if "64 nodes" in name else 1)
-    print(f"{name:40s} {per:7.1f} us/call (host)")
+    res[name.strip()] = round(per, 2)
+    print(f"{name:55s} {per:7.1f} us/call (host)", flush=True)
+out = os.path.join(ROOT, "gpurun_out")
+if os.path.isdir(out):
+    json.dump({"us_per_call_host": res, "stats": llm_qat_amd.stats()}, open(os.path.join(out, "host_overhead.json"), "w"), indent=1)

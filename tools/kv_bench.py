@@ -46,12 +46,12 @@ def raw_abi():
 
         def fwd_two(d):
             for t in "kv":
-                chk(L.fq_sym_fwd_autocast(d["x" + t].data_ptr(), d["y" + t].data_ptr(), rows, cols, 4, code, 1, -2.0, 2.0, d["s" + t].data_ptr(), None, 0, None, 0, st))
+                chk(L.fq_sym_fwd_autocast(d["x" + t].data_ptr(), d["y" + t].data_ptr(), rows, cols, 4, code, 1, 1, -2.0, 2.0, d["s" + t].data_ptr(), None, 0, None, 0, st))
 
         def fwd_pair(d):
             chk(L.fq_sym_fwd_pair(d["xk"].data_ptr(), d["yk"].data_ptr(), rows, 4, d["sk"].data_ptr(), d["sk"].data_ptr() + rows * 8, mb,
                                   d["xv"].data_ptr(), d["yv"].data_ptr(), rows, 4, d["sv"].data_ptr(), d["sv"].data_ptr() + rows * 8, mb,
-                                  cols, code, 0, 2, -2.0, 2.0, st))
+                                  cols, code, 1, 2, -2.0, 2.0, st))
 
         def bwd_two(d):  # bounds only: cast, then re-read x
             for t in "kv":

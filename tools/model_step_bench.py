@@ -91,7 +91,7 @@ def main():
     for wb, ab, kvb in ((4, 8, 4), (8, 8, 8))[: 1 if args.only else 2]:
         for ckpt in (False, True)[: 1 if args.only else 2]:
             for label, quant, wcache in (("no quantization (bf16 linears)", NoQuant, False), ("reference eager chain", TL.EagerQuant(), False),
-                                         ("llm_qat_amd", UQ, False), ("llm_qat_amd + sibling groups (opt-in)", UQ, False),
+                                         ("llm_qat_amd", UQ, False),
                                          ("llm_qat_amd + K/V in one launch", UQ, False),
                                          ("llm_qat_amd + weight cache", UQ, True),
                                          ("llm_qat_amd conservative (one launch + one node per reference call)", UQ, False)):
@@ -104,16 +104,14 @@ def main():
                     model = build(quant, args.layers, wb, ab, kvb)
                 llm_qat_amd.conservative("conservative" in label)
                 llm_qat_amd.enable_weight_quant_cache(wcache)
-                llm_qat_amd.group_siblings("sibling groups" in label and "groups off" not in label)
                 torch.cuda.reset_peak_memory_stats()
                 base = torch.cuda.memory_allocated()   # parameters (+ ids): the step's own peak is reported on top of this
 
-                def touch_weights():   # what an optimizer step does to the version counters: sibling groups learned in the
-                    with torch.no_grad():   # first step become active (llm-qat_amd/utils_quant.py, point 5)
+                def touch_weights():   # what an optimizer step does to the version counters (the weight cache's keys)
+                    with torch.no_grad():
                         for p in model.parameters():
                             p.mul_(1.0)
                 ms = timed(lambda: step(model, ids, ckpt), args.iters, touch_weights)
-                llm_qat_amd.group_siblings(False)   # the default
                 llm_qat_amd.conservative(False)
                 peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
                 llm_qat_amd.enable_weight_quant_cache(False)

@@ -1,4 +1,8 @@
-// fq_qlinear.hip -- SURVEY §8 f4a: QuantizeLinear's no-grad forward with the fake-quant applied WHILE THE GEMM LOADS ITS
+// fq_qlinear.hip -- EXPERIMENT, NOT PART OF THE PRODUCT LIBRARY (moved out of llm-qat_amd/csrc in round 4: measured slower than the
+// unfused product path -- fake-quant at the HBM roofline + hipBLASLt -- on every LLaMA shape; it is kept here, with
+// its tests and its bench, as the measured no-go it is).  Built by tools/qlinear/qlinear.py into tools/qlinear/libfq_qlinear_exp.so.
+//
+// QuantizeLinear's no-grad forward with the fake-quant applied WHILE THE GEMM LOADS ITS
 // OPERANDS (models/utils_quant.py:250  `F.linear(input_, weight)`  fed by :195-201 and :244-248).
 //
 //     out[tokens, out] = fq(x)[tokens, in] . fq(W)[out, in]^T          bf16 in, fp32 accumulate (MFMA), bf16 out
@@ -21,9 +25,30 @@
 
 #include <hip/hip_runtime.h>
 
-#include "fq_launch.h"
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../llm-qat_amd/csrc/fq_launch.h"
 
 using namespace fq;
+
+// the product's error plumbing lives in fq_api.hip; this stand-alone library carries its own copy of the two functions
+namespace {
+thread_local char g_qerr[320] = "";
+}
+namespace fq {
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_qerr, sizeof(g_qerr), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int ok() {
+    g_qerr[0] = 0;
+    return FQ_OK;
+}
+}  // namespace fq
 
 namespace {
 
@@ -256,6 +281,17 @@ template <int QA, int QW> int launch_ql(const QLArgs& a, int ablation, hipStream
 
 extern "C" {
 
+FQ_API const char* fq_qlinear_last_error(void) { return g_qerr; }
+
+/*
+ * out[tokens, out] = fq(x)[tokens, in] . fq(W)[out, in]^T   (models/utils_quant.py:195-201, :244-250), no backward.
+ *   x_scales / w_scales  per-row {s, t2} of the product's fq_sym_row_scales (float[rows][2]); NULL: that operand is multiplied AS IS
+ *   dtype      FQ_DTYPE_BF16 (operands and result);  autocast  1: the staged values follow fq_sym_fwd_autocast (rounded once to bf16)
+ *   dump_x / dump_w   optional [tokens, in] / [out, in] bf16 buffers receiving the operand tiles exactly as staged for the MFMAs
+ *   ablation   0; 1 / 2 are timing builds of the cost model (1: staging pipeline without MFMAs, 2: LDS reads + MFMAs without
+ *              staging) whose result is garbage
+ * FQ_ERR_UNSUPPORTED unless in_features % 64 == 0, out_features % 4 == 0, x / w 16-byte and out 8-byte aligned.
+ */
 FQ_API int fq_qlinear_fwd(const void* x, const float* x_scales, const void* w, const float* w_scales, void* out, int64_t tokens,
                           int64_t in_features, int64_t out_features, int dtype, int autocast, void* dump_x, void* dump_w, int ablation,
                           void* stream) {
@@ -280,7 +316,7 @@ FQ_API int fq_qlinear_fwd(const void* x, const float* x_scales, const void* w, c
     a.tiles_m = (int)((tokens + QL_BM - 1) / QL_BM);
     a.tiles_n = (int)((out_features + QL_BN - 1) / QL_BN);
     if ((int64_t)a.tiles_m * a.tiles_n > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "too many tiles");
-    clear_stale_error();
+    if (const int pending = pending_error()) return pending;
     hipStream_t st = (hipStream_t)stream;
     const int q = autocast ? 2 : 1;
     const int qa = x_scales ? q : 0, qw = w_scales ? q : 0;

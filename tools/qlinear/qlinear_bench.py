@@ -13,18 +13,22 @@ import os
 import statistics
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 from llm_qat_amd import _lib  # noqa: E402
+import qlinear as QX  # noqa: E402
 
 SHAPES = [("q/k/v/o_proj", 2048, 4096, 4096), ("gate/up_proj", 2048, 4096, 11008), ("down_proj", 2048, 11008, 4096)]
 
 
 def main():
     L = _lib.lib()
+    LQ = QX.lib()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     code = _lib.DTYPE_BF16
@@ -63,7 +67,7 @@ def main():
         def fused(qa, qw, abl=0, ac=0, xkey=None):
             def fn(s):
                 xk = xkey or ("x" if qa else "xq")
-                chk(L.fq_qlinear_fwd(s[xk].data_ptr(), s["xs"].data_ptr() if qa else None, (s["w"] if qw else s["wq"]).data_ptr(),
+                chk(LQ.fq_qlinear_fwd(s[xk].data_ptr(), s["xs"].data_ptr() if qa else None, (s["w"] if qw else s["wq"]).data_ptr(),
                                      s["ws"].data_ptr() if qw else None, s["o"].data_ptr(), m, k, n, code, ac, None, None, abl, st))
             return fn
 

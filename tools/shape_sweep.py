@@ -75,9 +75,9 @@ def main():
                 us_acn = us_acw = None
                 if kind == "sym" and esz == 2:   # the reference's arithmetic under torch.autocast (fp32 behind the reciprocal)
                     y32 = torch.empty(rows, cols, device=dev)
-                    us_acn = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, bits, code, 0, -2.0, 2.0,
+                    us_acn = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, bits, code, 1, 0, -2.0, 2.0,
                                                                     s["b"].data_ptr(), s["m"].data_ptr() if s["mb"] else None, s["mb"], None, 0, st)))
-                    us_acw = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), y32.data_ptr(), rows, cols, bits, code, 1, -2.0, 2.0,
+                    us_acw = t(lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), y32.data_ptr(), rows, cols, bits, code, 1, 1, -2.0, 2.0,
                                                                     s["b"].data_ptr(), None, 0, None, 0, st)))
                 row = dict(shape=label, dtype=str(dtype).split(".")[-1], kind=kind, bits=bits, elems=n, fwd_us=round(us_f, 2),
                            bwd_mask_us=round(us_b, 2), bwd_xread_us=round(us_bx, 2),

@@ -51,8 +51,8 @@ def main():
         "train_a8": lambda s: chk(L.fq_sym_fwd_train(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 0, -2.0, 2.0, s["b"].data_ptr(), s["m"].data_ptr(), mb, st)),
         "train_kv4": lambda s: chk(L.fq_sym_fwd_train(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 4, code, 0, -2.0, 2.0, s["b"].data_ptr(), s["m"].data_ptr(), mb, st)),
         "plain_a8": lambda s: chk(L.fq_sym_fwd(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 0, None, None, 0, st)),
-        "autocast_narrow_a8": lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 0, -2.0, 2.0, s["b"].data_ptr(), s["m"].data_ptr(), mb, None, 0, st)),
-        "autocast_narrow_a8_nomask": lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 0, -2.0, 2.0, None, None, 0, None, 0, st)),
+        "autocast_narrow_a8": lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 1, 0, -2.0, 2.0, s["b"].data_ptr(), s["m"].data_ptr(), mb, None, 0, st)),
+        "autocast_narrow_a8_nomask": lambda s: chk(L.fq_sym_fwd_autocast(s["x"].data_ptr(), s["y"].data_ptr(), rows, cols, 8, code, 1, 0, -2.0, 2.0, None, None, 0, None, 0, st)),
     }
     names = list(kinds)
     res = {k: [] for k in names}

@@ -266,15 +266,15 @@ def time_launches(torch, fn, iters, sets, name=None, fq_launches_per_call=1, min
     torch.cuda.synchronize()
     d = sorted(a.elapsed_time(b) for a, b in pairs)
     pct = [d[len(d) // 10], d[len(d) // 2], d[(9 * len(d)) // 10]]
-    return Timing(pct[1], pct, mean, iters, warm)
+    return Timing(mean, pct, iters, warm)
 
 
 class Timing(tuple):
-    """(ms, [p10, p50, p90]) as before -- ms is now the p50 of bracketed launches -- plus .mean_back_to_back / .iters / .warmup"""
+    """(mean ms of the back-to-back batch, [p10, p50, p90] ms of bracketed launches) + .iters / .warmup"""
 
-    def __new__(cls, ms, pct, mean, iters, warm):
+    def __new__(cls, ms, pct, iters, warm):
         t = super().__new__(cls, (ms, pct))
-        t.mean_back_to_back, t.iters, t.warmup = mean, iters, warm
+        t.iters, t.warmup = iters, warm
         return t
 
 
@@ -485,8 +485,7 @@ def roofline_entry(name, algorithmic_bytes, timing, traffic=None, moved_bytes=No
         e["traffic_source"] = traffic_source or "profiles/traffic.json"
     if pct:
         e["us_p10_p50_p90"] = [round(v * 1e3, 2) for v in pct]
-    if isinstance(timing, Timing):   # us_per_launch = p50 of `iters` individually bracketed launches after `warmup` warm-ups
-        e["us_mean_back_to_back"] = round(timing.mean_back_to_back * 1e3, 2)
+    if isinstance(timing, Timing):   # us_per_launch = mean over `iters` back-to-back launches after `warmup` warm-ups
         e["launches_timed"], e["warmup_launches"] = timing.iters, timing.warmup
     return e
 
@@ -1058,7 +1057,7 @@ def main(argv=None):
                                                     "achieved": round(moved_bytes_step_pd / (tot_us_pd * 1e-6) / 1e9, 1),
                                                     "frac": round(moved_bytes_step_pd / (tot_us_pd * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                                 "reference_dataflow_bytes_per_step": algo_bytes_step,
-                                "what": "both launches of the headline step (both gradients written): bytes moved / sum of the launches' p50 "
+                                "what": "both launches of the headline step (both gradients written): bytes moved / sum of the launches' "
                                         "times; product_default: the step with the weight's gradient in place"}
         out["unpaired_step"] = {"ms_per_step": None if args.core_extras else round(timed_region(wl.step_unpaired, it, 5, torch.cuda.synchronize) / it * 1e3, 4),
                                 "what": "the same step as four single-tensor launches (fq_sym_fwd_train x2, fq_ste_bwd_mask x2; weight gradient in place)"}

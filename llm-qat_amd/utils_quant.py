@@ -428,8 +428,9 @@ def _backward_started():
     """every fake-quant backward calls this first: results remembered before it (shared activations, a pending V of the K/V
     hooks) are never handed out afterwards -- their graphs may already be consumed"""
     _bwd_epoch[0] += 1
-    if getattr(_tls, "kv_stash", None) is not None:
-        _kv_discard()
+    if _kv_stash:   # (a plain dict keyed by the forward thread: the backward runs on the autograd engine's own thread)
+        for tid in list(_kv_stash):
+            _kv_discard(tid)
 
 
 def _act_lookup(key, x):
@@ -590,11 +591,14 @@ def _kv_state(clip_val, num_bits):
 
 
 _kv_off = set()   # call signatures whose speculation was thrown away once: they stop pairing
+_kv_stash = {}    # forward thread id -> (weakref(V), version, V's result, state, signature): the pending half of a K+V launch
 
 
-def _kv_discard():
+def _kv_discard(tid):
     """a V result nobody asked for: forget it (and its graph + side buffers), and stop guessing for that call signature"""
-    stash, _tls.kv_stash = _tls.kv_stash, None
+    stash = _kv_stash.pop(tid, None)
+    if stash is None:
+        return
     _count("kv_pair_discarded")
     if stash[4] not in _kv_off:
         _kv_off.add(stash[4])
@@ -606,14 +610,15 @@ def _kv_hook(x, clip_val, num_bits):
     if (not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 2 <= num_bits < 32 and x.dim() <= 3) or x.is_inference()
             or torch.compiler.is_compiling()):
         return None
-    stash = getattr(_tls, "kv_stash", None)
+    tid = threading.get_ident()
+    stash = _kv_stash.get(tid)
     if stash is not None:
         ref, ver, vq, state, sig = stash
         if ref() is x and ver == x._version and state == _kv_state(clip_val, num_bits):
-            _tls.kv_stash = None
+            del _kv_stash[tid]
             _count("kv_pair_hit")
             return vq   # V: quantized together with K a moment ago
-        _kv_discard()
+        _kv_discard(tid)
     rec = getattr(_tls, "outs", None)
     if not rec:
         return None
@@ -636,7 +641,7 @@ def _kv_hook(x, clip_val, num_bits):
                 return None
             _count("kv_pair_launch")
             kq, vq = _PairNode.apply(x, v, res, (lo, hi)) if need else (res[0], res[1])
-            _tls.kv_stash = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits), sig)
+            _kv_stash[tid] = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits), sig)
             return kq
     return None
 
@@ -644,6 +649,7 @@ def _kv_hook(x, clip_val, num_bits):
 def reset_learned_state():
     """forget what the host logic has learned about call sites (today: K/V signatures that stopped pairing)"""
     _kv_off.clear()
+    _kv_stash.clear()
 
 
 def conservative(flag=True):

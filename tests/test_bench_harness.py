@@ -210,7 +210,7 @@ def test_self_check_flags_round_3s_headline_and_passes_the_like_for_like_one():
 
 
 def test_kernel_timing_protocol_is_independent_of_steps():
-    """every per-kernel entry: >= 200 launches after >= 20 warm-ups whatever --steps says; us_per_launch = p50 of bracketed launches"""
+    """every per-kernel entry: >= 200 launches after >= 20 warm-ups whatever --steps says; us_per_launch = their back-to-back mean"""
     class _Ev:
         clock = [0.0]
 
@@ -243,7 +243,7 @@ def test_kernel_timing_protocol_is_independent_of_steps():
     t = bench.time_launches(_Torch, fn, 20, [0, 1, 2, 3], name="k")        # the driver's --steps 20
     assert t.iters >= 200 and t.warmup >= 20 and len(calls) == t.warmup + 2 * t.iters
     ms, pct = t
-    assert abs(ms - 0.05) < 1e-9 and pct[1] == ms and t.mean_back_to_back > ms
+    assert abs(pct[1] - 0.05) < 1e-9 and abs(ms - (0.05 * 0.9 + 0.5 * 0.1)) < 1e-6
     assert bench.PROFILE_MANIFEST[-1] == ("k", t.warmup + 2 * t.iters)
     e = bench.roofline_entry("k", 1000, t)
-    assert e["launches_timed"] >= 200 and e["warmup_launches"] >= 20 and e["us_per_launch"] == 50.0
+    assert e["launches_timed"] >= 200 and e["warmup_launches"] >= 20 and abs(e["us_per_launch"] - 95.0) < 0.01

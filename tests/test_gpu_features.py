@@ -674,7 +674,7 @@ def test_kv_speculation_stops_after_a_wrong_guess_and_says_so(pkg):
         k_only_step()
     st = pkg.stats()
     assert st.get("kv_pair_launch") == 1 and st.get("kv_pair_discarded") == 1 and st.get("kv_pair_learned_off") == 1 and not st.get("kv_pair_hit"), st
-    assert getattr(U._tls, "kv_stash", None) is None, "the unused V result stayed pinned after the backward"
+    assert not U._kv_stash, "the unused V result stayed pinned after the backward"
     n_first = c.n
     with Counter(pkg.ops, ["pair_forward"]) as c:
         k_only_step()
@@ -1150,6 +1150,9 @@ def test_inplace_weight_gradient_is_guarded(pkg):
     assert not U._owns_storage(flat[8:].view(128, 512))
     with torch.autograd.detect_anomaly(check_nan=False):
         assert not U._inplace_ok(g)
+    pkg.stats(reset=True)
+    assert not U._inplace_ok(g) and pkg.stats().get("inplace_refused:storage_refs") == 1   # `v` above still aliases g's storage (round 4: the storage's own holders count)
+    del v
     assert U._inplace_ok(g)
     # an alias made WITHOUT view tracking (its own TensorImpl, no _base) shares the storage: the storage's own holder
     # count shows it

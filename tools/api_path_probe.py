@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Where the module path's time goes on the metric tensors: host time of forward / backward separately, GPU time by events,
+and the kernels one step launches (run under `rocprofv3 --kernel-trace --stats` for the list)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import llm_qat_amd  # noqa: E402
+from llm_qat_amd.utils_quant import QuantizeLinear  # noqa: E402
+
+dev = torch.device("cuda:0")
+rows, cols = 4096, 11008
+nsets = 4
+
+
+class _NoGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        return torch.empty_like(x), torch.empty_like(w)
+
+
+lins = []
+for k in range(nsets):
+    lin = QuantizeLinear(cols, rows, w_bits=4, a_bits=8).to(device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.normal_(0, 0.02)
+    a = torch.randn(rows, cols, device=dev).bfloat16().requires_grad_(True)
+    lins.append((lin, a))
+go = torch.empty(rows, rows, dtype=torch.bfloat16, device=dev)
+real = F.linear
+F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
+N = int(os.environ.get("N", "40"))
+tf = tb = 0.0
+for k in range(8):
+    lin, a = lins[k % nsets]
+    lin.weight.grad = a.grad = None
+    lin(a).backward(go)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t_all = time.perf_counter()
+e0.record()
+for k in range(N):
+    lin, a = lins[k % nsets]
+    lin.weight.grad = a.grad = None
+    t0 = time.perf_counter()
+    out = lin(a)
+    t1 = time.perf_counter()
+    out.backward(go)
+    t2 = time.perf_counter()
+    tf += t1 - t0
+    tb += t2 - t1
+e1.record()
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t_all
+print(f"host forward {tf / N * 1e6:.1f} us, host backward {tb / N * 1e6:.1f} us, wall {t_all / N * 1e6:.1f} us/step, GPU events {e0.elapsed_time(e1) / N * 1e3:.1f} us/step")
+print(llm_qat_amd.stats())
+# weight.grad: is it the GEMM's own output (handed on by reference) or a clone?
+lin, a = lins[0]
+print("weight.grad data_ptr unique per step (no clone expected):", lin.weight.grad.data_ptr())
+F.linear = torch.nn.functional.linear = real

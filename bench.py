@@ -721,13 +721,22 @@ def api_path(wl, iters=60):
         lins.append((lin, s["a"].detach().requires_grad_(True)))
     go = torch.empty(tokens, wl.rows, dtype=torch.bfloat16, device=dev)
 
-    def one(k):
-        lin, a = lins[k % len(lins)]
-        lin.weight.grad = a.grad = None
-        lin(a).backward(go)
+    class _Floor(torch.nn.Module):   # what PyTorch itself costs for a module of this shape: module call, one autograd Function, two leaves, the engine
+        def __init__(self, lin):
+            super().__init__()
+            self.weight = lin.weight
 
-    def timed(n):
-        for k in range(5):
+        def forward(self, x):
+            return F.linear(x, self.weight)
+
+    floors = [(_Floor(lin), a) for lin, a in lins]
+
+    def timed(n, mods=lins):
+        def one(k):
+            m, a = mods[k % len(mods)]
+            m.weight.grad = a.grad = None
+            m(a).backward(go)
+        for k in range(8):
             one(k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -737,13 +746,14 @@ def api_path(wl, iters=60):
         return (time.perf_counter() - t0) / n
 
     real = F.linear
-    llm_qat_amd.stats(reset=True)
     F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
     try:
+        dt_floor = timed(iters, floors)
+        llm_qat_amd.stats(reset=True)
         dt = timed(iters)
+        st = llm_qat_amd.stats()
     finally:
         F.linear = torch.nn.functional.linear = real
-    st = llm_qat_amd.stats()
     dt_gemm = timed(max(10, iters // 4))
     flops = 3 * 2.0 * tokens * wl.cols * wl.rows
     return {"ms_per_step": round(dt * 1e3, 4), "value": round(2 * wl.n / dt / 1e9, 2), "unit": "Gelem/s",
@@ -751,6 +761,9 @@ def api_path(wl, iters=60):
                     "no-launch stand-in: 1 pair forward launch + 1 pair backward launch (weight gradient in place), wall clock incl. Python / "
                     "autograd / allocator",
             "stats": {k: v for k, v in st.items() if k.startswith(("pair_", "single_", "inplace_"))},
+            "pytorch_floor_ms_per_step": round(dt_floor * 1e3, 4),
+            "pytorch_floor_what": "the same loop with a plain module whose forward is only the no-launch stand-in (module call + one autograd Function + "
+                                  "engine + two AccumulateGrad, no fake-quant): what PyTorch costs on this host before this library does anything",
             "with_gemm": {"ms_per_step": round(dt_gemm * 1e3, 4), "gemm_tflops_equiv": round(flops / dt_gemm / 1e12, 1),
                           "what": "the same call with the real F.linear (forward GEMM + dgrad + wgrad, hipBLASLt)"}}
 

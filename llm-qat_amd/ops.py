@@ -60,6 +60,16 @@ def _prep(x, what):
     return code
 
 
+def _on_device(x, call):
+    """run `call(stream)` with x's device current (the common case -- it already is -- costs one C call)"""
+    idx = x.device.index
+    cur = _cur_dev()
+    if idx is None or idx == cur:
+        return call(_raw_stream(cur))
+    with torch.cuda.device(idx):
+        return call(_raw_stream(idx))
+
+
 class _DeviceOf:
     """Make x's device current for the launch if it is not already."""
 
@@ -312,18 +322,21 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     if ac and not wide and not autocast_narrow_ok(w):
         return None  # autocast dtype != operand dtype: the two-call path returns fp32 results, F.linear rounds once
     L = _lib.lib()
-    odt = torch.float32 if wide else w.dtype
-    wq, xq = torch.empty(w.shape, dtype=odt, device=w.device), torch.empty(x.shape, dtype=odt, device=w.device)
+    if wide:
+        wq, xq = torch.empty(w.shape, dtype=torch.float32, device=w.device), torch.empty(x.shape, dtype=torch.float32, device=w.device)
+    else:
+        wq, xq = torch.empty_like(w), torch.empty_like(x)
     side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device) if need_w else None
     side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device) if need_x else None
     pw, px = (side_w.data_ptr() if need_w else None), (side_x.data_ptr() if need_x else None)
-    with _DeviceOf(w):
-        rc = L.fq_sym_fwd_pair(w.data_ptr(), wq.data_ptr(), rows_w, int(w_bits), pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
-                               x.data_ptr(), xq.data_ptr(), rows_x, int(a_bits), px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
-                               cols, code, _SEM_AUTOCAST if ac else _semantics, (2 if wide else 1) if ac else 0, float(lo), float(hi), _stream(w))
-    if rc == _lib.ERR_UNSUPPORTED:
-        return None
-    _lib.check(rc, "quantize_pair")
+    rc = _on_device(w, lambda st: L.fq_sym_fwd_pair(
+        w.data_ptr(), wq.data_ptr(), rows_w, w_bits, pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
+        x.data_ptr(), xq.data_ptr(), rows_x, a_bits, px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
+        cols, code, _SEM_AUTOCAST if ac else _semantics, (2 if wide else 1) if ac else 0, lo, hi, st))
+    if rc:
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, "quantize_pair")
     return wq, xq, side_w, side_x, rows_w, rows_x, cols
 
 
@@ -338,12 +351,13 @@ def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, inplace_
     gw, gx = _aligned(gw), _aligned(gx)
     ow, ox = (gw if inplace_w else torch.empty_like(gw)), torch.empty_like(gx)
     pw, px = side_w.data_ptr(), side_x.data_ptr()
-    with _DeviceOf(gw):
-        rc = _lib.lib().fq_ste_bwd_mask_pair(gw.data_ptr(), ow.data_ptr(), rows_w, pw, pw + rows_w * 8,
-                                             gx.data_ptr(), ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, float(lo), float(hi), code, _stream(gw))
-    if rc == _lib.ERR_UNSUPPORTED:
-        return train_backward(gw, side_w, rows_w, cols, lo, hi, inplace=inplace_w), train_backward(gx, side_x, rows_x, cols, lo, hi)
-    _lib.check(rc, "quantize_linear_pair_backward")
+    L = _lib.lib()
+    rc = _on_device(gw, lambda st: L.fq_ste_bwd_mask_pair(gw.data_ptr(), ow.data_ptr(), rows_w, pw, pw + rows_w * 8,
+                                                          gx.data_ptr(), ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, lo, hi, code, st))
+    if rc:
+        if rc == _lib.ERR_UNSUPPORTED:
+            return train_backward(gw, side_w, rows_w, cols, lo, hi, inplace=inplace_w), train_backward(gx, side_x, rows_x, cols, lo, hi)
+        _lib.check(rc, "quantize_linear_pair_backward")
     return ow, ox
 
 

@@ -444,16 +444,13 @@ def _act_lookup(key, x):
 
 
 def _act_store(key, x, y):
+    """One entry per key: the next module that quantizes an activation with the same settings -- the next layer's q_proj / gate_proj --
+    replaces it, so at most one fake-quantized activation per key outlives its siblings (until the next forward).  A dead input
+    can never match (`rin() is x` on a dead weak reference is False), so id reuse is harmless."""
     cache = getattr(_tls, "act", None)
     if cache is None:
         cache = _tls.act = {}
-
-    def _drop(ref, cache=cache, key=key):  # the input died: nobody can ask for this result again
-        ent = cache.get(key)
-        if ent is not None and ent[0] is ref:
-            del cache[key]
-
-    cache[key] = (weakref.ref(x, _drop), x._version, y, y._version, _bwd_epoch[0])
+    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch[0])
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
@@ -494,7 +491,7 @@ class _PairNode(torch.autograd.Function):
         ctx.wide = wq.dtype != weight.dtype  # fp32 results under autocast (the K / V hooks): fp32 gradients come back
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
-        wq, xq = wq.view_as(wq), xq.view_as(xq)
+        # (wq / xq are fresh tensors of the launch that nothing else refers to: they become this node's outputs as they are)
         # An operand that needs no gradient (frozen weight, input without grad) gets a result that needs none either, as
         # SymQuantizer.apply gives in the reference: F.linear's backward then skips the wgrad / dgrad GEMM it would
         # otherwise run only for this node to throw the result away.

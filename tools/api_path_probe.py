@@ -41,6 +41,45 @@ go = torch.empty(rows, rows, dtype=torch.bfloat16, device=dev)
 real = F.linear
 F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
 N = int(os.environ.get("N", "40"))
+
+
+class _Floor(torch.nn.Module):   # what PyTorch itself costs for a module of this shape: one autograd Function, two leaves
+    def __init__(self, lin):
+        super().__init__()
+        self.weight = lin.weight
+
+    def forward(self, x):
+        return F.linear(x, self.weight)
+
+
+def loop(mods, n):
+    tf = tb = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_all = time.perf_counter()
+    e0.record()
+    for k in range(n):
+        m, a = mods[k % nsets]
+        m.weight.grad = a.grad = None
+        t0 = time.perf_counter()
+        out = m(a)
+        t1 = time.perf_counter()
+        out.backward(go)
+        t2 = time.perf_counter()
+        tf += t1 - t0
+        tb += t2 - t1
+    e1.record()
+    torch.cuda.synchronize()
+    return tf / n * 1e6, tb / n * 1e6, (time.perf_counter() - t_all) / n * 1e6, e0.elapsed_time(e1) / n * 1e3
+
+
+floors = [(_Floor(l), a) for l, a in lins]
+loop(floors, 8)
+print("floor (module + one no-launch Function + engine): host fwd %.1f us, host bwd %.1f us, wall %.1f us/step, GPU %.1f us/step" % loop(floors, N))
+for name, setup in (("default", lambda: llm_qat_amd.conservative(False)), ("conservative", lambda: llm_qat_amd.conservative(True))):
+    setup()
+    loop(lins, 8)
+    print("%-12s host fwd %.1f us, host bwd %.1f us, wall %.1f us/step, GPU %.1f us/step" % ((name,) + loop(lins, N)))
+llm_qat_amd.conservative(False)
 tf = tb = 0.0
 for k in range(8):
     lin, a = lins[k % nsets]

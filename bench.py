@@ -1304,17 +1304,17 @@ def lowbit_asym_specs(wl, fused_only=False):
         return fn
 
     def w12_fused(bits):
-        return lambda s: chk(L.fq_w12_fwd_rows(s["w"].data_ptr(), s["yw"].data_ptr(), s["sc16"].data_ptr(), rows, cols, bits, code, 0, st))
+        return lambda s: chk(L.fq_w12_fwd_rows(s["w"].data_ptr(), s["yw"].data_ptr(), s["sc16"].data_ptr(), rows, cols, bits, code, st))
 
     t2 = 2048
 
     def asym(s):
         chk(L.fq_asym_fwd_train(s["a"].data_ptr(), s["ya"].data_ptr(), t2, cols, 8, code, 0, -2.0, 2.0, s["ba"].data_ptr(), s["ma"].data_ptr(), wl.mask_bytes, st))
 
-    ks = [("w12 1-bit default: ATen abs+mean + fq_w12_fwd (3 launches, ~10 B/elem moved)", w12_default(1), n * 4, n * 10),
-          ("w12 2-bit default: ATen abs+mean + fq_w12_fwd (3 launches, ~10 B/elem moved)", w12_default(2), n * 4, n * 10),
-          ("w12 1-bit one launch (opt-in, in-kernel row mean)", w12_fused(1), n * 4, n * 4),
-          ("w12 2-bit one launch (opt-in, in-kernel row mean)", w12_fused(2), n * 4, n * 4),
+    ks = [("w12 1-bit as three launches: ATen abs+mean + fq_w12_fwd (~10 B/elem moved; the default until round 3)", w12_default(1), n * 4, n * 10),
+          ("w12 2-bit as three launches: ATen abs+mean + fq_w12_fwd (~10 B/elem moved; the default until round 3)", w12_default(2), n * 4, n * 10),
+          ("w12 1-bit one launch (product default: row mean in ATen's summation order)", w12_fused(1), n * 4, n * 4),
+          ("w12 2-bit one launch (product default: row mean in ATen's summation order)", w12_fused(2), n * 4, n * 4),
           ("asym_fwd_a8 bf16 [2048,11008] (training mode)", asym, t2 * cols * 4, t2 * cols * 4 + t2 * cols // 8)]
     if fused_only:
         ks = ks[2:]

@@ -35,7 +35,8 @@ extern "C" {
 
 #define FQ_ABI_VERSION 4 /* 2: + multi-tensor launches, export, row scales, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap;
                             4: fq_sym_fwd_autocast takes `sem` (and the autocast modes of pair / multi / export / row_scales honour it),
-                               FQ_ERR_PENDING, fq_qlinear_fwd (an experiment with test hooks in its signature) left the library */
+                               FQ_ERR_PENDING, fq_qlinear_fwd (an experiment with test hooks in its signature) left the library, fq_w12_fwd_rows sums
+                               in ATen's own order (no `sem`) */
 
 /* element types */
 #define FQ_DTYPE_F32 0
@@ -253,16 +254,17 @@ int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows, int64_
                int dtype, void* stream);
 
 /*
- * The same branches with the per-row scale reduced INSIDE the kernel (per-row `abs().mean(dim=1)`, :205-209 / :219-224;
- * weight_layerwise is not served): one launch, read w + write out, instead of ATen's abs + mean + fq_w12_fwd.
- * OPT-IN: the mean is a floating-point sum and this kernel's summation order is its own, not ATen's -- for bf16 / fp16
- * tensors the scale (rounded to the tensor dtype) differs from ATen's for about one row in a few thousand, for fp32 in the
- * last bit routinely; fq_w12_fwd with ATen's own reduction stays the bit-exact default.
+ * The same branches in ONE launch (read w + write out instead of ATen's abs + mean + fq_w12_fwd: ~10 B/elem in three launches), with the
+ * per-row scale `abs().mean(dim=1)` (:205-209 / :219-224; weight_layerwise is not served) reduced INSIDE the kernel IN ATen'S OWN
+ * SUMMATION ORDER -- the fixed tree torch's GPU reduce kernel uses for a contiguous [rows, cols] tensor (groups of 4 elements,
+ * four sequential fp32 accumulators per thread, the ROCm shuffle order, the 8-wave combine, the multiply by float(1/cols)) -- so the
+ * scale, and with it every output element, is bit-identical to the reference's eager ops on this device.  (ABI <= 3 had an opt-in
+ * kernel with its own summation order here, one bf16 ulp off ATen's on <= 0.5 % of the rows; the `sem` parameter left with it.)
  *   scale_out  optional [rows] values of `dtype`: the scaling factor used (mean|w|, or 2*mean|w| for 2 bits)
- *   sem        FQ_SEM_CPU_EAGER: mean = sum / n;  FQ_SEM_DEVICE_EAGER: mean = sum * (1/n), as ATen's GPU kernel
- * FQ_ERR_UNSUPPORTED unless rows are 16-byte aligned, cols a multiple of a 16-byte vector and <= 8192 vectors.
+ * FQ_ERR_UNSUPPORTED where that order is not the restated one or the row does not fit the kernel's registers: rows < 8, cols < 256,
+ * cols % 4 != 0, tensors not 16-byte aligned, cols > 32768, fp32 with 4096 < cols <= 8128 -- callers then use ATen + fq_w12_fwd.
  */
-int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int dtype, int sem, void* stream);
+int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int dtype, void* stream);
 
 /*
  * ---- the integer side of the fake-quant forward ---------------------------------------------------------

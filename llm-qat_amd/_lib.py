@@ -93,7 +93,7 @@ def _bind(L):
     L.fq_asym_export.restype = i32
     L.fq_sym_row_scales.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, f32, f32, vp, vp, sz, vp]
     L.fq_sym_row_scales.restype = i32
-    L.fq_w12_fwd_rows.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    L.fq_w12_fwd_rows.argtypes = [vp, vp, vp, i64, i64, i32, i32, vp]
     L.fq_w12_fwd_rows.restype = i32
     L.fq_sym_fwd_multi.argtypes = [i32, ctypes.POINTER(FwdTensor), i64, i32, i32, i32, f32, f32, vp]
     L.fq_sym_fwd_multi.restype = i32

@@ -285,19 +285,18 @@ FQ_API int fq_w12_fwd(const void* w, const void* scale, void* out, int64_t rows,
     }
 }
 
-FQ_API int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int dtype, int sem, void* stream) {
+FQ_API int fq_w12_fwd_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int dtype, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (w_bits != 1 && w_bits != 2) return fail(FQ_ERR_BITS, "w_bits=%d: this entry point serves 1 and 2", w_bits);
-    if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
     if (rows == 0 || cols == 0) return ok();
     if (!w || !out) return fail(FQ_ERR_NULL, "w / out must not be NULL");
     const float cv = (float)(1.0 - 1e-2);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case FQ_DTYPE_F32: return launch_w12_rows<F32>(w, out, scale_out, rows, cols, w_bits, sem, cv, st);
-        case FQ_DTYPE_F16: return launch_w12_rows<F16>(w, out, scale_out, rows, cols, w_bits, sem, cv, st);
-        default: return launch_w12_rows<BF16>(w, out, scale_out, rows, cols, w_bits, sem, cv, st);
+        case FQ_DTYPE_F32: return launch_w12_rows<F32>(w, out, scale_out, rows, cols, w_bits, cv, st);
+        case FQ_DTYPE_F16: return launch_w12_rows<F16>(w, out, scale_out, rows, cols, w_bits, cv, st);
+        default: return launch_w12_rows<BF16>(w, out, scale_out, rows, cols, w_bits, cv, st);
     }
 }
 

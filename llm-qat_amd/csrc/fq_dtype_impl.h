@@ -366,43 +366,41 @@ int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_
     return launch_result();
 }
 
+// The one-launch 1-/2-bit branch with ATen's own summation order (w12_row_aten_kernel): served where that order is the restated one --
+// contiguous rows >= 8, cols >= 256, cols % 4 == 0, 16-byte aligned tensors, rows that fit the kernel's registers.
 template <int DT>
-int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st) {
+int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, float cv, hipStream_t st) {
     using T = Ty<DT>;
-    constexpr int EPV = 16 / T::ESIZE;
-    if (const int pending = pending_error()) return pending;
-    const int64_t nvec = cols / EPV;
-    if (!(aligned16(w) && aligned16(out) && cols % EPV == 0 && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "fused 1-/2-bit branch: rows must be 16-byte aligned and fit the register kernels");
+    if (!(aligned16(w) && aligned16(out) && cols % 4 == 0 && cols >= 256 && rows >= 8))
+        return fail(FQ_ERR_UNSUPPORTED, "one-launch 1-/2-bit branch: needs rows >= 8, cols >= 256, cols %% 4 == 0 and 16-byte aligned tensors");
     if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);
-    const bool dev = sem == FQ_SEM_DEVICE_EAGER;
-    const int64_t bytes = rows * cols * T::ESIZE;
-    const int nt = bytes >= NT_LOAD_MIN_BYTES ? 2 : bytes >= NT_STORE_MIN_BYTES ? 1 : 0;  // cache policy as launch_reg's
-#define K(TPR, V, WB, DEV)                                                                                                                   \
-    {                                                                                                                                        \
-        const int64_t grid = TPR == 64 ? (rows + 3) / 4 : rows;                                                                              \
-        constexpr int BLK = TPR == 64 ? 256 : TPR;                                                                                           \
-        if (nt == 2) FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, true, true>), grid, BLK, st, w, out, scale_out, rows, cols, cv);          \
-        else if (nt == 1) FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, false, true>), grid, BLK, st, w, out, scale_out, rows, cols, cv);    \
-        else FQ_LAUNCH((w12_row_kernel<DT, WB, TPR, V, DEV, false, false>), grid, BLK, st, w, out, scale_out, rows, cols, cv);                \
+    const int64_t ngroups = cols / 4;
+    const bool shared_row = cols >= 8129;                      // ATen: values_per_thread = ceil(cols / 64) >= 128 splits a row across the 8 waves
+    const int64_t gpt = shared_row ? (ngroups + 511) / 512 : (ngroups + 63) / 64;   // groups per ATen thread
+    constexpr int MAXG_OWN = DT == F32 ? 16 : 32;              // fp32 groups are 4 VGPRs each
+    if (gpt > (shared_row ? 16 : MAXG_OWN) || (shared_row && (cols + 511) / 512 >= 256))
+        return fail(FQ_ERR_UNSUPPORTED, "one-launch 1-/2-bit branch: cols=%lld outside the row lengths this kernel holds in registers", (long long)cols);
+    if (const int pending = pending_error()) return pending;
+    const float factor = (float)rows / (float)(rows * cols);   // ATen: static_cast<float>(num_outputs) / numel
+    const bool ntl = rows * cols * T::ESIZE >= NT_LOAD_MIN_BYTES;
+    const int64_t grid = shared_row ? rows : (rows + 7) / 8;
+#define K(SH, G, WB)                                                                                                              \
+    {                                                                                                                             \
+        if (ntl) FQ_LAUNCH((w12_row_aten_kernel<DT, WB, SH, G, true, true>), grid, 512, st, w, out, scale_out, rows, cols, cv, factor);   \
+        else FQ_LAUNCH((w12_row_aten_kernel<DT, WB, SH, G, false, true>), grid, 512, st, w, out, scale_out, rows, cols, cv, factor);      \
     }
-#define R(TPR, V)                                                    \
-    case V:                                                          \
-        if (w_bits == 1) {                                           \
-            if (dev) K(TPR, V, 1, true) else K(TPR, V, 1, false)     \
-        } else {                                                     \
-            if (dev) K(TPR, V, 2, true) else K(TPR, V, 2, false)     \
-        }                                                            \
-        break;
-    if (nvec <= 256) {
-        switch ((int)((nvec + 63) / 64)) { R(64, 1) R(64, 2) R(64, 3) R(64, 4) }
-    } else if (nvec <= 1024) {
-        switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) R(256, 4) }
-    } else if (nvec <= 4096) {
-        switch ((int)((nvec + 511) / 512)) { R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+#define KW(SH, G)                    \
+    {                                \
+        if (w_bits == 1) K(SH, G, 1) \
+        else K(SH, G, 2)             \
+    }
+    if (shared_row) {
+        if (gpt <= 6) KW(true, 6) else if (gpt <= 8) KW(true, 8) else KW(true, 16)
     } else {
-        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+        if (gpt <= 16) KW(false, 16)
+        else if constexpr (DT != F32) KW(false, 32)
     }
-#undef R
+#undef KW
 #undef K
     return launch_result();
 }
@@ -415,6 +413,6 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
     template int launch_ste_mask<DT>(SteLaunch, int64_t, float, float, hipStream_t);                             \
     template int launch_ste_mask_wide<DT>(SteLaunch, int64_t, float, float, hipStream_t);                        \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);     \
-    template int launch_w12_rows<DT>(const void*, void*, void*, int64_t, int64_t, int, int, float, hipStream_t);
+    template int launch_w12_rows<DT>(const void*, void*, void*, int64_t, int64_t, int, float, hipStream_t);
 
 }  // namespace fq

@@ -909,78 +909,115 @@ __global__ __launch_bounds__(256) void w12_kernel(const void* __restrict__ w, co
     }
 }
 
-// 1-/2-bit weight branch in ONE pass (opt-in): the per-row mean|w| scale is reduced here, in fp32, in this kernel's own
-// summation order (thread-sequential over its 16-byte vectors, butterfly across the wave, then across waves), instead of
-// by ATen's `abs().mean(dim=1)` -- one launch and 4 B/elem (bf16) instead of three launches and ~10 B/elem.  A
-// floating-point sum depends on its order: for 16-bit tensors the fp32 sum is rounded to 8 / 11 significant bits, so two
-// orders disagree only when the sum lies within ~2^-20 of a rounding boundary (about one row in a few thousand); for fp32
-// tensors the last bit differs routinely.  That is why this path is opt-in and ATen's reduction stays the default.
-template <int DT, int WBITS, int TPR, int VPT, bool DEVSEM, bool NTL = false, bool NTS = false>
-__global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void w12_row_kernel(const void* __restrict__ w, void* __restrict__ out, void* __restrict__ scale_out,
-                                                                        int64_t rows, int64_t cols, float cv) {
+// ------------------------------------------------------------------------------------
+// The 1-/2-bit weight branch in ONE launch (read w, write out) with the per-row mean summed IN ATen'S OWN ORDER, so that the scale is
+// bit-identical to what the reference computes on this device (`torch.mean(abs(w), dim=1, keepdim=True)`, utils_quant.py:205-209 /
+// :219-224) and the one-launch path can be the default.  ATen's GPU reduction is a fixed tree for a given shape (third-party
+// arithmetic, restated from torch 2.10's aten/src/ATen/native/cuda/Reduce.cuh: setReduceConfig, input_vectorized_thread_reduce_impl,
+// block_x_reduce with its ROCm shuffle order, block_y_reduce, MeanOps::project; pinned by tests/test_gpu_features.py
+// ::test_low_bit_fused_row_mean against live ATen: 0 differing rows).  For a contiguous [rows >= 8, cols] tensor with cols >= 256,
+// cols % 4 == 0, reduced over its last dimension, ATen launches 512 threads as 8 waves of 64 lanes:
+//   * elements are consumed in groups of 4 (ATen's input vector); ATen thread T owns groups T, T + S, T + 2S, ... and keeps FOUR
+//     fp32 accumulators, one per position in the group, each summed sequentially from +0; then ((a0 + a1) + a2) + a3;
+//   * cols <= 8128 (ATen's values_per_thread < 128): every wave reduces its OWN row, S = 64, T = lane;
+//     cols >= 8129: the 8 waves share one row, S = 512, T = wave * 64 + lane;
+//   * across the 64 lanes: v += shfl_down(v, 1), then 2, 4, ... 32 (increasing offsets on ROCm) -- lane 0 ends up with the
+//     balanced tree over the lanes in order;  across the 8 waves (shared rows): ((y0 + y4) + (y2 + y6)) + ((y1 + y5) + (y3 + y7));
+//   * mean = sum * float(1 / cols) (MeanOps::project: a multiply by the fp32 factor), rounded once to the tensor dtype.
+// This kernel gives thread T exactly ATen thread T's elements: groups of 4 (8-byte accesses for 16-bit tensors, 16-byte for fp32),
+// MAXG >= groups per thread held in registers; groups past the row's end are not loaded and add +0.
+// (Rounds 2-3 had an opt-in kernel with its own summation order: <= 0.5 % of the rows of a [4096,11008] bf16 weight came out one
+// bf16 ulp off ATen's, so it could not be the default; it is gone.)
+// ------------------------------------------------------------------------------------
+template <int DT> struct AtenGroup {   // bf16 / fp16: 4 elements = 8 bytes
+    typedef uint2 type;
+    template <bool NT> __device__ static __forceinline__ uint2 ld(const void* p, int64_t g) { return ld8<NT>((const uint2*)p + g); }
+    template <bool NT> __device__ static __forceinline__ void st(void* p, int64_t g, uint2 v) { st8<NT>((uint2*)p + g, v); }
+    __device__ static __forceinline__ void abs4(const uint2& v, float (&a)[4]) {
+        float lo[2], hi[2];
+        Ty<DT>::unpack(v.x, lo);
+        Ty<DT>::unpack(v.y, hi);
+        a[0] = __builtin_fabsf(lo[0]), a[1] = __builtin_fabsf(lo[1]), a[2] = __builtin_fabsf(hi[0]), a[3] = __builtin_fabsf(hi[1]);
+    }
+};
+template <> struct AtenGroup<F32> {    // 4 elements = 16 bytes
+    typedef uint4 type;
+    template <bool NT> __device__ static __forceinline__ uint4 ld(const void* p, int64_t g) { return ld16<NT>((const uint4*)p + g); }
+    template <bool NT> __device__ static __forceinline__ void st(void* p, int64_t g, uint4 v) { st16<NT>((uint4*)p + g, v); }
+    __device__ static __forceinline__ void abs4(const uint4& v, float (&a)[4]) {
+        a[0] = __builtin_fabsf(as_f(v.x)), a[1] = __builtin_fabsf(as_f(v.y)), a[2] = __builtin_fabsf(as_f(v.z)), a[3] = __builtin_fabsf(as_f(v.w));
+    }
+};
+
+template <int DT, int WBITS, bool SHARED_ROW, int MAXG, bool NTL, bool NTS>
+__global__ __launch_bounds__(512) void w12_row_aten_kernel(const void* __restrict__ w, void* __restrict__ out, void* __restrict__ scale_out,
+                                                           int64_t rows, int64_t cols, float cv, float factor /* fp32 1 / cols */) {
     using T = Ty<DT>;
-    constexpr int EPV = 16 / T::ESIZE;
-    constexpr int NW = TPR / 64;
-    __shared__ float red[NW > 1 ? NW : 1];
-    int64_t row;
-    int t;
-    if constexpr (TPR == 64) {
-        row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        t = threadIdx.x & 63;
-        if (row >= rows) return;
-    } else {
-        row = blockIdx.x;
-        t = threadIdx.x;
-    }
-    const int nvec = (int)(cols / EPV);
-    const uint4* __restrict__ xr = (const uint4*)((const char*)w + row * cols * T::ESIZE);
-    uint4* __restrict__ yr = (uint4*)((char*)out + row * cols * T::ESIZE);
-    uint4 r[VPT];
-    float acc = 0.f;
+    using G = AtenGroup<DT>;
+    typedef typename G::type group_t;
+    __shared__ float ysum[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = SHARED_ROW ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 8 + wave;
+    const int tid = SHARED_ROW ? (int)threadIdx.x : lane;     // ATen's thread index within the row's reduction
+    constexpr int STEP = SHARED_ROW ? 512 : 64;
+    if (!SHARED_ROW && row >= rows) return;                   // wave-uniform
+    const int ngroups = (int)(cols / 4);
+    const char* xr = (const char*)w + row * cols * T::ESIZE;
+    char* yr = (char*)out + row * cols * T::ESIZE;
+    group_t r[MAXG];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int v = t + i * TPR;
-        r[i] = ld16<NTL>(&xr[v < nvec ? v : nvec - 1]);
-        const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            float f[T::EPD];
-            T::unpack(wd[d], f);
-#pragma unroll
-            for (int k = 0; k < T::EPD; ++k) acc += (v < nvec) ? __builtin_fabsf(f[k]) : 0.f;
-        }
+    for (int k = 0; k < MAXG; ++k) {   // groups past the row's end are not loaded: they stay +0 and add nothing
+        const int g = tid + k * STEP;
+        r[k] = group_t{};
+        if (g < ngroups) r[k] = G::template ld<NTL>(xr, g);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if constexpr (NW > 1) {
-        if ((t & 63) == 0) red[t >> 6] = acc;
+    for (int k = 0; k < MAXG; ++k) {   // sequential in k, one accumulator per position in the group: ATen's value_list[0..3]
+        float a[4];
+        G::abs4(r[k], a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = acc[i] + a[i];
+    }
+    float v = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_down(v, o, 64);   // block_x_reduce, ROCm order; lane 0 holds the wave's sum
+    if constexpr (SHARED_ROW) {
+        if (lane == 0) ysum[wave] = v;
         __syncthreads();
-        acc = red[0];
-#pragma unroll
-        for (int i = 1; i < NW; ++i) acc += red[i];
+        v = ((ysum[0] + ysum[4]) + (ysum[2] + ysum[6])) + ((ysum[1] + ysum[5]) + (ysum[3] + ysum[7]));   // block_y_reduce
+    } else {
+        v = __shfl(v, 0, 64);
     }
-    // torch.mean: CPU divides the sum by n, the GPU kernel multiplies by a float 1/n
-    float sc = T::rb(DEVSEM ? acc * (1.0f / (float)cols) : acc / (float)cols);
+    float sc = T::rb(v * factor);
     if constexpr (WBITS == 2) sc = T::rb(2.0f * sc);
-    if (t == 0 && scale_out) T::store1(scale_out, row, sc);
+    if (tid == 0 && scale_out) T::store1(scale_out, row, sc);
     const W12Row wr = w12_row<DT>(sc, cv);
-    if (wr.mk) {  // wave-uniform: an ordinary scale (every row of a real weight)
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = t + i * TPR;
-            const uint4 o = w12_vec<DT, WBITS>(r[i], wr, cv);
-            if (v < nvec) st16<NTS>(&yr[v], o);
+    for (int k = 0; k < MAXG; ++k) {
+        const int g = tid + k * STEP;
+        group_t o;
+        if constexpr (DT == F32) {
+            o = wr.mk ? w12_vec<DT, WBITS>(r[k], wr, cv)
+                      : make_uint4(w12_dword_any<DT, WBITS>(r[k].x, wr, cv), w12_dword_any<DT, WBITS>(r[k].y, wr, cv),
+                                   w12_dword_any<DT, WBITS>(r[k].z, wr, cv), w12_dword_any<DT, WBITS>(r[k].w, wr, cv));
+        } else {
+            if (wr.mk) {   // row-uniform: an ordinary scale (every row of a real weight)
+                bool odd = false;
+                o.x = w12_dword<DT, WBITS>(r[k].x, wr, odd);
+                o.y = w12_dword<DT, WBITS>(r[k].y, wr, odd);
+                if constexpr (DT == BF16 && WBITS == 1) {
+                    if (__builtin_amdgcn_ballot_w64(odd) != 0) {   // practically never taken: redo with the reference chain op for op
+                        o.x = w12_dword_any<DT, WBITS>(r[k].x, wr, cv);
+                        o.y = w12_dword_any<DT, WBITS>(r[k].y, wr, cv);
+                    }
+                }
+            } else {       // zero / NaN / infinite / extreme scale
+                o.x = w12_dword_any<DT, WBITS>(r[k].x, wr, cv);
+                o.y = w12_dword_any<DT, WBITS>(r[k].y, wr, cv);
+            }
         }
-    } else {      // zero / NaN / infinite / extreme scale: the reference chain op for op
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = t + i * TPR;
-            const uint32_t wd[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-            uint32_t o[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = w12_dword_any<DT, WBITS>(wd[d], wr, cv);
-            if (v < nvec) st16<NTS>(&yr[v], make_uint4(o[0], o[1], o[2], o[3]));
-        }
+        if (g < ngroups) G::template st<NTS>(yr, g, o);
     }
 }
 

@@ -169,7 +169,7 @@ template <int DT>
 FQ_HIDDEN int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row,
                          float cv, hipStream_t st);
 template <int DT>
-FQ_HIDDEN int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, int sem, float cv, hipStream_t st);
+FQ_HIDDEN int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int64_t cols, int w_bits, float cv, hipStream_t st);
 // words (uint64) of STE mask per row -- a plain bitmap, one bit per element, rows padded to 8 bytes; 0 if the shape is not
 // served by the mask path (the recording kernels are the register-resident ones: whole 16-byte vectors, rows that fit)
 inline int64_t mask_row_words(int64_t cols, int esize) {

@@ -496,15 +496,16 @@ def low_bit_weight(w, scale, w_bits):
 
 
 def low_bit_weight_fused(w, w_bits):
-    """The 1-/2-bit branch in ONE launch, per-row mean|w| reduced inside the kernel (fq_w12_fwd_rows): -> (out, scale[rows])
-    or None when the shape is not served.  The scale's fp32 summation order is the kernel's own, not ATen's (see the header)."""
+    """The 1-/2-bit branch in ONE launch, per-row mean|w| reduced inside the kernel in ATen's own summation order (fq_w12_fwd_rows):
+    bit-identical to `abs().mean(dim=1)` + the elementwise chain on this device.  -> (out, scale[rows]) or None when the shape is not
+    served (the caller then takes ATen's reduction + fq_w12_fwd)."""
     code = _prep(w, "low_bit_weight_fused")
-    if w.dim() != 2 or not w.is_contiguous() or w.numel() == 0:
+    if code == _lib.DTYPE_F64 or w.dim() != 2 or not w.is_contiguous() or w.numel() == 0:
         return None
     out = torch.empty_like(w)
     scale = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
-    with _DeviceOf(w):
-        rc = _lib.lib().fq_w12_fwd_rows(w.data_ptr(), out.data_ptr(), scale.data_ptr(), w.shape[0], w.shape[1], int(w_bits), code, _semantics, _stream(w))
+    L = _lib.lib()
+    rc = _on_device(w, lambda st: L.fq_w12_fwd_rows(w.data_ptr(), out.data_ptr(), scale.data_ptr(), w.shape[0], w.shape[1], int(w_bits), code, st))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "low_bit_weight_fused")

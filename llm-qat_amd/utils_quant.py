@@ -237,7 +237,7 @@ class _LowBitWeight(torch.autograd.Function):
 
 
 class _LowBitWeightFused(torch.autograd.Function):
-    """the same value from the one-launch kernel (its own row mean); identity gradient"""
+    """the same value from the one-launch kernel (row mean in ATen's order); identity gradient"""
 
     @staticmethod
     def forward(ctx, w, w_bits):
@@ -255,9 +255,11 @@ class _NotServed(Exception):
     pass
 
 
-# 1-/2-bit weights in one launch with the row mean reduced in-kernel: OPT-IN (LLMQAT_AMD_W12_FUSED=1 / fuse_low_bit_mean),
-# because a float sum's order is the kernel's own -- the default keeps ATen's reduction and is bit-exact to the reference.
-_W12_FUSED = os.environ.get("LLMQAT_AMD_W12_FUSED", "0") == "1"
+# 1-/2-bit weights in ONE launch with the row mean reduced in-kernel IN ATen'S OWN SUMMATION ORDER (fq_w12_fwd_rows): bit-identical to
+# `abs().mean(dim=1)` + the elementwise chain on this device, so it is the default since round 4 (LLMQAT_AMD_W12_FUSED=0 /
+# fuse_low_bit_mean(False) go back to ATen's abs + mean followed by fq_w12_fwd: three launches).  Shapes the kernel does not serve
+# (weight_layerwise, rows < 8, cols < 256 or not a multiple of 4, ...) take those three launches anyway.
+_W12_FUSED = os.environ.get("LLMQAT_AMD_W12_FUSED", "1") != "0"
 
 
 def fuse_low_bit_mean(flag=True):
@@ -652,8 +654,7 @@ def reset_learned_state():
 def conservative(flag=True):
     """One switch for "the reference's structure, only faster": with it on, every reference call is exactly one kernel launch and one
     autograd node, gradients are written out of place, and nothing is remembered between calls -- no operand pairing, no shared
-    activation fake-quant, no K/V pairing at the hooks, no weight cache, no sibling groups, no fused GEMM, no in-place weight
-    gradient.  Results are bit-identical either way (tests/test_tiny_llama.py::test_conservative_mode_is_bit_identical); the switch
+    activation fake-quant, no K/V pairing at the hooks, no weight cache, no in-place weight gradient.  Results are bit-identical either way (tests/test_tiny_llama.py::test_conservative_mode_is_bit_identical); the switch
     exists to take the stateful host logic out of the picture when debugging a training run.  `conservative(False)` restores the
     defaults (not the environment's settings).  Environment: LLMQAT_AMD_CONSERVATIVE=1."""
     pair_operands(not flag)
@@ -662,7 +663,6 @@ def conservative(flag=True):
     inplace_weight_grad(not flag)
     if flag:
         enable_weight_quant_cache(False)
-        fuse_low_bit_mean(False)
 
 
 if os.environ.get("LLMQAT_AMD_CONSERVATIVE", "0") == "1":
@@ -729,10 +729,9 @@ class QuantizeLinear(nn.Linear):
         self._act_kind = "sym" if symmetric else "asym"  # what torch.compile's trace reads (a class identity test does not trace)
 
     def _low_bit_weight(self, w):
-        """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding, identity
-        gradient (the reference's detach trick).  The mean stays ATen's reduction (a sum is order dependent;
-        this keeps the scale bit-identical to the reference's); the ~10 elementwise kernels after it are one
-        HIP kernel."""
+        """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding, identity gradient (the reference's
+        detach trick).  One launch where the kernel reproduces ATen's summation order (a sum is order dependent: that keeps the scale
+        bit-identical to the reference's on this device); otherwise ATen's own abs + mean, then the ~10 elementwise kernels as one."""
         if _W12_FUSED and not self.weight_layerwise and w.is_cuda and w.is_contiguous():
             try:
                 return _LowBitWeightFused.apply(w, self.w_bits)

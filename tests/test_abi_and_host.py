@@ -233,7 +233,8 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     t = (_lib.FwdTensor * 5)()
     assert L.fq_sym_fwd_multi(5, t, 64, 1, 0, 0, -2.0, 2.0, None) == -7                                   # at most 4 tensors
     assert L.fq_sym_fwd_multi(2, t, 64, 1, 0, 0, -2.0, 2.0, None) in (-2, -3, -4)                         # zeroed descriptors are rejected
-    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, 0, None) == -2
+    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, None) == -2
+    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 1, 1, None) == -8        # rows < 8 / cols < 256: ATen's reduce configuration is another one there
     assert b"bits" in L.fq_last_error() or b"w_bits" in L.fq_last_error()
 
 
@@ -242,17 +243,15 @@ def test_conservative_switch_turns_every_stateful_host_optimisation_off_and_back
     (the GPU tier checks that results stay bit-identical: tests/test_tiny_llama.py::test_conservative_mode_is_bit_identical)"""
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
-    names = ("_PAIR", "_SHARE_ACT", "_PAIR_KV", "_INPLACE_WGRAD", "_WEIGHT_CACHE", "_W12_FUSED")
+    names = ("_PAIR", "_SHARE_ACT", "_PAIR_KV", "_INPLACE_WGRAD", "_WEIGHT_CACHE")
     before = {n: getattr(UQ, n) for n in names}
     try:
         llm_qat_amd.enable_weight_quant_cache(True)
-        llm_qat_amd.fuse_low_bit_mean(True)
         llm_qat_amd.conservative(True)
         assert not any(getattr(UQ, n) for n in names), {n: getattr(UQ, n) for n in names}
         llm_qat_amd.conservative(False)
         assert UQ._PAIR and UQ._SHARE_ACT and UQ._PAIR_KV and UQ._INPLACE_WGRAD      # the defaults
-        assert not (UQ._WEIGHT_CACHE or UQ._W12_FUSED)   # opt-ins stay off
+        assert not UQ._WEIGHT_CACHE   # opt-ins stay off
     finally:
         UQ._PAIR, UQ._SHARE_ACT, UQ._PAIR_KV, UQ._INPLACE_WGRAD = before["_PAIR"], before["_SHARE_ACT"], before["_PAIR_KV"], before["_INPLACE_WGRAD"]
         llm_qat_amd.enable_weight_quant_cache(before["_WEIGHT_CACHE"])
-        llm_qat_amd.fuse_low_bit_mean(before["_W12_FUSED"])

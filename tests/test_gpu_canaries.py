@@ -163,7 +163,7 @@ def test_round2_entry_points_stay_inside_their_buffers(dtype, code, es):
             if mb:
                 ok(L.fq_sym_row_scales(x.ptr, scales.ptr, rows, cols, 8, code, 0, 0, -2.0, 2.0, bounds.ptr, mask.ptr, mb, st), "row_scales + mask", allow=(-8,))
             for wb in (1, 2):
-                ok(L.fq_w12_fwd_rows(x.ptr, y.ptr, sc16.ptr, rows, cols, wb, code, 0, st), "w12_fwd_rows", allow=(-8,))
+                ok(L.fq_w12_fwd_rows(x.ptr, y.ptr, sc16.ptr, rows, cols, wb, code, st), "w12_fwd_rows", allow=(-8,))
             if mb and off == 0:
                 for nt in (3, 4):
                     rws = [rows, max(1, rows // 2), rows + 1, 2][:nt]

@@ -233,8 +233,8 @@ def test_round2_entry_points_validate_arguments_without_a_gpu():
     t = (_lib.FwdTensor * 5)()
     assert L.fq_sym_fwd_multi(5, t, 64, 1, 0, 0, -2.0, 2.0, None) == -7                                   # at most 4 tensors
     assert L.fq_sym_fwd_multi(2, t, 64, 1, 0, 0, -2.0, 2.0, None) in (-2, -3, -4)                         # zeroed descriptors are rejected
-    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, None) == -2
     assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 1, 1, None) == -8        # rows < 8 / cols < 256: ATen's reduce configuration is another one there
+    assert L.fq_w12_fwd_rows(bad, bad, None, 4, 64, 3, 1, None) == -2
     assert b"bits" in L.fq_last_error() or b"w_bits" in L.fq_last_error()
 
 

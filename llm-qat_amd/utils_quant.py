@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 from torch.autograd.function import once_differentiable
 
-from . import compiled, ops
+from . import compiled, cpu_tensors, ops
 
 # How the backward learns which gradients to zero (results are identical in all three modes):
 #   "mask"   (default) the forward records per-row value bounds + a 1-bit/element STE mask for rows
@@ -116,6 +116,12 @@ class _FakeQuantFunction(torch.autograd.Function):
             ctx.fq_mode = "compiled"
             return compiled.fake_quant(kind, input, clip_val, num_bits, layerwise, narrow)
         ctx.grad_dtype = None
+        if input.device.type == "cpu":   # opt-in, plain torch ops (cpu_tensors.py): never a fallback for a CUDA tensor
+            if not cpu_tensors.ENABLED:
+                cpu_tensors.refuse(input, f"{kind}_quantize")
+            ctx.fq_mode = "cpu"
+            ctx.save_for_backward(input, clip_val)   # reference :45 / :104
+            return cpu_tensors.forward(kind, input, num_bits, layerwise)
         if not ctx.needs_input_grad[0]:  # no backward will run (eval, frozen input): nothing to record or save
             ctx.fq_mode = "none"
             if kind == "sym" and ops.autocast_active(input):
@@ -154,6 +160,9 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "compiled":
             input, clip_val = ctx.saved_tensors
             return compiled.fake_quant_bwd(grad_output, input, clip_val), None, None, None
+        if ctx.fq_mode == "cpu":
+            input, clip_val = ctx.saved_tensors
+            return cpu_tensors.backward(grad_output, input, clip_val), None, None, None
         inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
         _backward_started()
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
@@ -221,6 +230,18 @@ class AsymQuantizer(_FakeQuantFunction):
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
         return _FakeQuantFunction._fwd("asym", ctx, input, clip_val, num_bits, layerwise)
+
+
+class _LowBitWeightCpu(torch.autograd.Function):
+    """the same branch for CPU tensors (opt-in, cpu_tensors.py); identity gradient"""
+
+    @staticmethod
+    def forward(ctx, w, w_bits, layerwise):
+        return cpu_tensors.low_bit_weight(w, w_bits, layerwise)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None, None
 
 
 class _LowBitWeight(torch.autograd.Function):
@@ -732,6 +753,10 @@ class QuantizeLinear(nn.Linear):
         """1- and 2-bit branches (reference :202-242): mean-|w| scale, sign / 2-level rounding, identity gradient (the reference's
         detach trick).  One launch where the kernel reproduces ATen's summation order (a sum is order dependent: that keeps the scale
         bit-identical to the reference's on this device); otherwise ATen's own abs + mean, then the ~10 elementwise kernels as one."""
+        if w.device.type == "cpu":
+            if not cpu_tensors.ENABLED:
+                cpu_tensors.refuse(w, "low_bit_weight")
+            return _LowBitWeightCpu.apply(w, self.w_bits, self.weight_layerwise)
         if _W12_FUSED and not self.weight_layerwise and w.is_cuda and w.is_contiguous():
             try:
                 return _LowBitWeightFused.apply(w, self.w_bits)

@@ -109,6 +109,7 @@ def test_module_surface_matches_reference():
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():
+    """the default: CPU tensors are refused (the opt-in torch-op path for them is tests/test_cpu_tensors.py)"""
     from llm_qat_amd.utils_quant import QuantizeLinear, SymQuantizer
     with pytest.raises(RuntimeError, match="no CPU"):
         SymQuantizer.apply(torch.randn(4, 8), torch.tensor([-2.0, 2.0]), 8, False)

@@ -8,6 +8,11 @@ namespace fq {
 
 #define FQ_LAUNCH(kern, grid, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, st, __VA_ARGS__)
 
+// Which (threads per row, 16-byte vectors per thread) the model widths select (bf16 / fp16: 8 elements per vector):
+//   4096 -> 512 vectors -> 256 x 2     5120 -> 640 -> 256 x 3     11008 -> 1376 -> 512 x 3     13824 -> 1728 -> 512 x 4
+//   tiny-LLaMA (fp32, 4 per vector): 256 -> 64 x 1, 688 -> 64 x 3.      Every other width is served by the nearest shape that holds it.
+// Round 4 pruned the instantiations nothing selects often enough to deserve its own code (27 MB / 100 s of build in round 3): stores
+// are always non-temporal (two cache-policy flavours instead of three), 5 / 7 vectors per thread share the 6 / 8 kernels.
 // Launch shape of the register-resident kernel, from tools/kbench on MI355X: 2-3 vectors per
 // thread is the sweet spot (round 3 re-checked with block sizes that are not powers of two -- 704 x 2 for 11008 cols wastes 2 % of
 // the vector slots instead of 10 %, 576 x 3 for 13824, 320 x 2 for 5120 -- and with 256 x 6 for mid-sized tensors: within +-2 % of
@@ -26,10 +31,10 @@ static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
         switch ((int)((nvec + 127) / 128)) { R(128, 2) R(128, 3) }
     } else if (nvec <= 768) {
         switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) }
-    } else if (nvec <= 4096) {
-        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+    } else if (nvec <= 4096) {   // (5 and 7 vectors per thread run as 6 and 8: no model width lands there, see the table above launch_reg)
+        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) case 5: R(512, 6) case 7: R(512, 8) }
     } else {
-        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+        switch ((int)((nvec + 1023) / 1024)) { case 5: R(1024, 6) case 7: R(1024, 8) }
     }
 #undef R
 }
@@ -47,10 +52,10 @@ static void launch_reg_ac(const RowArgs& a, int64_t nvec, hipStream_t st) {
         switch ((int)((nvec + 127) / 128)) { R(128, 2) R(128, 3) }
     } else if (nvec <= 768) {
         switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) }
-    } else if (nvec <= 4096) {
-        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+    } else if (nvec <= 4096) {   // (5 and 7 vectors per thread run as 6 and 8: no model width lands there, see the table above launch_reg)
+        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) case 5: R(512, 6) case 7: R(512, 8) }
     } else {
-        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+        switch ((int)((nvec + 1023) / 1024)) { case 5: R(1024, 6) case 7: R(1024, 8) }
     }
 #undef R
 }
@@ -66,7 +71,7 @@ static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
         if (mask) FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, true>), grid, BLOCK, st, a);     \
         else FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, false>), grid, BLOCK, st, a);         \
         break;
-        H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(8)
+        H(1) H(2) H(3) H(4) H(5) H(6) case 7: H(8)
 #undef H
         default: break;
     }
@@ -93,13 +98,12 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
             const bool wide_ok = aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8 &&
                                  more_aligned(a, 7u, 15u);
             if (wide_ok) {
-                const bool nts = 3 * bytes >= NT_STORE_MIN_BYTES, ntl = bytes >= NT_LOAD_MIN_BYTES;
+                const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define W(TPR)                                                                                          \
     {                                                                                                   \
         const int hpt = (int)((nh + TPR - 1) / TPR);                                                    \
         if (ntl) launch_wide<DT, TPR, true, true>(a, hpt, st);                                          \
-        else if (nts) launch_wide<DT, TPR, false, true>(a, hpt, st);                                    \
-        else launch_wide<DT, TPR, false, false>(a, hpt, st);                                            \
+        else launch_wide<DT, TPR, false, true>(a, hpt, st);                                             \
     }
                 if (nh <= 512) W(64) else if (nh <= 2048) W(256) else W(1024)
 #undef W
@@ -120,8 +124,7 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         if (AC == 1 && vec_ok && nvec <= REG_MAX_VEC) {
             if constexpr (AC == 1) {
                 if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
-                else if (bytes >= NT_STORE_MIN_BYTES) launch_reg_ac<DT, AC, false, true>(a, nvec, st);
-                else launch_reg_ac<DT, AC, false, false>(a, nvec, st);
+                else launch_reg_ac<DT, AC, false, true>(a, nvec, st);
             }
         } else if (a.mask) {
             return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
@@ -160,7 +163,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     const int64_t nvec = a.cols / EPV;
     const int64_t big_rows = largest_rows(a);
     const int64_t bytes = big_rows * a.cols * T::ESIZE;  // cache policy follows the larger tensor
-    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
     bool two_pass = false, two_pass_vec = false;
     if (pair && !(vec_ok && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
     if (vec_ok && nvec <= REG_MAX_VEC) {
@@ -169,8 +172,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         // kernels carry none of that code; it runs the same arithmetic with the default cache policy
         if (a.idx || a.scale) launch_reg<DT, ASYM, FAST, false, false, true>(a, nvec, st);
         else if (ntl) launch_reg<DT, ASYM, FAST, true, true, false>(a, nvec, st);
-        else if (nts) launch_reg<DT, ASYM, FAST, false, true, false>(a, nvec, st);
-        else launch_reg<DT, ASYM, FAST, false, false, false>(a, nvec, st);
+        else launch_reg<DT, ASYM, FAST, false, true, false>(a, nvec, st);
     } else if (a.mask) {
         return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
     } else if (vec_ok) {
@@ -225,10 +227,8 @@ template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t
         const int64_t bytes = n * T::ESIZE;
         if (bytes >= NT_LOAD_MIN_BYTES)
             FQ_LAUNCH((ste_vec_kernel<DT, 1, true, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
-        else if (bytes >= NT_STORE_MIN_BYTES)
-            FQ_LAUNCH((ste_vec_kernel<DT, 1, false, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
         else
-            FQ_LAUNCH((ste_vec_kernel<DT, 1, false, false>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
+            FQ_LAUNCH((ste_vec_kernel<DT, 1, false, true>), grid, STE_THREADS, st, (const uint4*)g, (const uint4*)x, (uint4*)gx, nvec, lo, hi);
     } else {
         int64_t grid = (n + STE_THREADS - 1) / STE_THREADS;
         if (grid > 8192) grid = 8192;
@@ -252,12 +252,11 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     const int vpt = (cv + STE_THREADS - 1) / STE_THREADS;
     if (rows * chunks > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows*chunks exceeds the grid limit");
     const int64_t bytes = rows * cols * T::ESIZE;
-    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define S(V)                                                                                                                              \
     case V:                                                                                                                               \
         if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);        \
-        else if (nts) FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);  \
-        else FQ_LAUNCH((ste_rows_kernel<DT, V, false, false>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);          \
+        else FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);           \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -302,12 +301,11 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
     for (int i = 0; i < L.n; ++i)
         if (!L.t[i].inplace && L.t[i].rows > big_rows) big_rows = L.t[i].rows;
     const int64_t bytes = big_rows * cols * T::ESIZE;
-    const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= NT_STORE_MIN_BYTES;
+    const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define S(V)                                                                                                               \
     case V:                                                                                                                \
         if (ntl) FQ_LAUNCH2((ste_mask_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);        \
-        else if (nts) FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);  \
-        else FQ_LAUNCH2((ste_mask_kernel<DT, V, false, false>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);          \
+        else FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);           \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -333,12 +331,11 @@ template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, 
         const int64_t grid = ste_layout(L, false);
         if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows exceed the grid limit");
         const int64_t bytes = largest_rows(L) * cols * 4;  // the fp32 gradient is the larger stream
-        const bool ntl = bytes >= NT_LOAD_MIN_BYTES, nts = bytes >= 2 * NT_STORE_MIN_BYTES;
+        const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define S(V)                                                                                                                  \
     case V:                                                                                                                   \
         if (ntl) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);        \
-        else if (nts) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);  \
-        else FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, false>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);          \
+        else FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);           \
         break;
         switch (hpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S

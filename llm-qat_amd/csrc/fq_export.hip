@@ -25,9 +25,9 @@ template <int DT, bool ASYM, bool NTL> void launch_export_reg(const ExportArgs& 
     } else if (nvec <= 768) {
         switch ((int)((nvec + 255) / 256)) { R(256, 2) R(256, 3) }
     } else if (nvec <= 4096) {
-        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) R(512, 5) R(512, 6) R(512, 7) R(512, 8) }
+        switch ((int)((nvec + 511) / 512)) { R(512, 2) R(512, 3) R(512, 4) case 5: R(512, 6) case 7: R(512, 8) }
     } else {
-        switch ((int)((nvec + 1023) / 1024)) { R(1024, 5) R(1024, 6) R(1024, 7) R(1024, 8) }
+        switch ((int)((nvec + 1023) / 1024)) { case 5: R(1024, 6) case 7: R(1024, 8) }
     }
 #undef R
 }

@@ -72,32 +72,24 @@ inline int64_t largest_rows(const SteLaunch& L) {
 }
 
 // Cache policy of the 16-byte streams, from tools/kbench on MI355X (every tensor is touched once per launch):
-//  * stores: non-temporal from 4 MiB up (a tensor that size cannot stay in an XCD's 4 MiB L2 anyway).  NT stores
-//    win at every size measured: 16 MB forward 7.3 -> 5.9 us, 45 MB 17.9 -> 14.2 us, 90 MB 34.3 -> 31.9 us.
+//  * stores: always non-temporal.  NT stores win at every size measured from 4 MiB up (16 MB forward 7.3 -> 5.9 us, 45 MB 17.9 -> 14.2 us,
+//    90 MB 34.3 -> 31.9 us); below that a launch is latency-bound either way, so since round 4 there is no cacheable-store flavour
+//    of the kernels (a third fewer instantiations).
 //  * loads: non-temporal only from 72 MiB up.  Below that the input was typically produced by the kernel just
 //    before and still sits in the 256 MiB Infinity Cache, where plain loads are faster (16 MB: 5.9 vs 6.1 us,
 //    45 MB: 14.2 vs 16.1 us, 67 MB: 20.4 vs 22.2 us); the big MLP weights come from HBM, where NT loads are faster
 //    (84 MB: 27.8 vs 28.8 us, 90 MB: 30.3 vs 31.3 us, 113 MB: 37.0 vs 38.0 us).
-// Tuning overrides (read once per process, MiB): LLMQAT_FQ_NT_STORE_MIN_MB / LLMQAT_FQ_NT_LOAD_MIN_MB.  A load threshold
-// below the store threshold is raised to it (the kernels come in three cache-policy flavours: none, stores, both).
+// Tuning override (read once per process, MiB): LLMQAT_FQ_NT_LOAD_MIN_MB.
 inline int64_t nt_env_mib(const char* name, int64_t dflt) {
     const char* v = getenv(name);
     if (!v || !*v) return dflt << 20;
     const long long mb = atoll(v);
     return (mb < 0 ? dflt : (int64_t)mb) << 20;
 }
-inline int64_t nt_store_min_bytes() {
-    static const int64_t v = nt_env_mib("LLMQAT_FQ_NT_STORE_MIN_MB", 4);
-    return v;
-}
 inline int64_t nt_load_min_bytes() {
-    static const int64_t v = [] {
-        const int64_t l = nt_env_mib("LLMQAT_FQ_NT_LOAD_MIN_MB", 72), s = nt_store_min_bytes();
-        return l < s ? s : l;
-    }();
+    static const int64_t v = nt_env_mib("LLMQAT_FQ_NT_LOAD_MIN_MB", 72);
     return v;
 }
-#define NT_STORE_MIN_BYTES (::fq::nt_store_min_bytes())
 #define NT_LOAD_MIN_BYTES (::fq::nt_load_min_bytes())
 
 constexpr int64_t REG_MAX_VEC = 1024 * 8;    // longest row (in 16-byte vectors) the register kernels hold

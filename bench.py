@@ -731,6 +731,8 @@ def api_path(wl, iters=60):
 
     floors = [(_Floor(lin), a) for lin, a in lins]
 
+    last = {}
+
     def timed(n, mods=lins):
         def one(k):
             m, a = mods[k % len(mods)]
@@ -739,11 +741,17 @@ def api_path(wl, iters=60):
         for k in range(8):
             one(k)
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record()
         for k in range(n):
             one(k)
+        e1.record()
+        t_host = time.perf_counter() - t0      # everything enqueued
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+        dt = (time.perf_counter() - t0) / n
+        last.update(host=t_host / n, gpu=e0.elapsed_time(e1) * 1e-3 / n)
+        return dt
 
     real = F.linear
     F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
@@ -751,6 +759,7 @@ def api_path(wl, iters=60):
         dt_floor = timed(iters, floors)
         llm_qat_amd.stats(reset=True)
         dt = timed(iters)
+        host_ms, gpu_ms = last["host"] * 1e3, last["gpu"] * 1e3
         st = llm_qat_amd.stats()
     finally:
         F.linear = torch.nn.functional.linear = real
@@ -761,6 +770,7 @@ def api_path(wl, iters=60):
                     "no-launch stand-in: 1 pair forward launch + 1 pair backward launch (weight gradient in place), wall clock incl. Python / "
                     "autograd / allocator",
             "stats": {k: v for k, v in st.items() if k.startswith(("pair_", "single_", "inplace_"))},
+            "host_ms_per_step": round(host_ms, 4), "gpu_span_ms_per_step": round(gpu_ms, 4),
             "pytorch_floor_ms_per_step": round(dt_floor * 1e3, 4),
             "pytorch_floor_what": "the same loop with a plain module whose forward is only the no-launch stand-in (module call + one autograd Function + "
                                   "engine + two AccumulateGrad, no fake-quant): what PyTorch costs on this host before this library does anything",

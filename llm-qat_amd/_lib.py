@@ -7,7 +7,9 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libllmqat_fakequant.so")
+# LLMQAT_AMD_LIB points the loader at another build of the library (A/B runs of kernel variants: tools/ab_bench.sh) -- the product
+# file is never overwritten; fq_build_info() / LIB_PATH say which one is loaded
+LIB_PATH = os.environ.get("LLMQAT_AMD_LIB") or os.path.join(HERE, "libllmqat_fakequant.so")
 ABI_VERSION = 4
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3

@@ -272,8 +272,16 @@ def build_bwd():
 # QuantizeLinear fixtures (utils_quant.py:165-254)
 # --------------------------------------------------------------------------------------
 def build_linear():
+    import torch.nn.functional as F
     arrays, manifest = {}, []
     gen = torch.Generator().manual_seed(2024)
+    captured = {}
+    real_linear = F.linear
+
+    def spy(inp, weight, bias=None):   # the operands exactly as the module hands them to the GEMM (round 4: pins them at module level)
+        captured["x"], captured["w"] = inp.detach().clone(), weight.detach().clone()
+        return real_linear(inp, weight, bias)
+
     combos = [
         dict(w_bits=4, a_bits=8, symmetric=True),
         dict(w_bits=8, a_bits=8, symmetric=True),
@@ -299,7 +307,11 @@ def build_linear():
             w[4, 6] = -2.0
             lin.weight.data = w.to(dt)
             x = act_like(gen, (2, 5, in_f), dt).requires_grad_(True)
-            out = lin(x)
+            F.linear = torch.nn.functional.linear = spy
+            try:
+                out = lin(x)
+            finally:
+                F.linear = torch.nn.functional.linear = real_linear
             go = (torch.randn(out.shape, generator=gen) * 0.1).to(dt)
             out.backward(go)
             name = f"lin_{dname}_{ci}"
@@ -309,6 +321,8 @@ def build_linear():
             arrays[f"{name}/out"] = to_np(out)
             arrays[f"{name}/gw"] = to_np(lin.weight.grad)
             arrays[f"{name}/gx"] = to_np(x.grad)
+            arrays[f"{name}/opx"] = to_np(captured["x"])
+            arrays[f"{name}/opw"] = to_np(captured["w"])
             manifest.append(dict(name=name, dtype=dname, in_features=in_f, out_features=out_f, **kw))
     return arrays, manifest
 

@@ -107,9 +107,17 @@ def _autograd_golden(G, SymQuantizer, AsymQuantizer):
 def test_quantize_linear_golden(ops):
     """QuantizeLinear drop-in: same ctor, state_dict == ['weight'], outputs/grads match the reference's.
     The GEMM (F.linear) is rocBLAS on the device vs MKL on the CPU, so out/grads are compared with a
-    tolerance; the fake-quantized operands themselves are covered bit-exactly by the tests above."""
+    tolerance; the OPERANDS the module hands to the GEMM are compared bit for bit with the reference's own
+    (`opx` / `opw` in the fixture, round 4)."""
+    import torch.nn.functional as F
     from llm_qat_amd.utils_quant import QuantizeLinear
     G = golden("quantize_linear.npz")
+    real, seen = F.linear, {}
+
+    def spy(inp, weight, bias=None):
+        seen["x"], seen["w"] = inp.detach().clone(), weight.detach().clone()
+        return real(inp, weight, bias)
+
     for c in G.cases:
         dt = c["dtype"]
         kw = {k: c[k] for k in ("w_bits", "a_bits", "symmetric", "act_layerwise", "weight_layerwise") if k in c}
@@ -118,7 +126,14 @@ def test_quantize_linear_golden(ops):
         lin = lin.cuda()
         lin.weight.data = dev_from(G.arr(c, "w"), dt)
         x = dev_from(G.arr(c, "x"), dt).requires_grad_(True)
-        out = lin(x)
+        F.linear = torch.nn.functional.linear = spy
+        try:
+            out = lin(x)
+        finally:
+            F.linear = torch.nn.functional.linear = real
+        if c["w_bits"] >= 3:   # (the 1-/2-bit scale is a float SUM: the device's differs from the CPU fixture's in the last place)
+            assert bits_equal(np_from(seen["w"]), G.arr(c, "opw"), dt), f"{c['name']}: weight operand {mismatch_report(np_from(seen['w']), G.arr(c, 'opw'), dt)}"
+        assert bits_equal(np_from(seen["x"]), G.arr(c, "opx"), dt), f"{c['name']}: input operand {mismatch_report(np_from(seen['x']), G.arr(c, 'opx'), dt)}"
         out.backward(dev_from(G.arr(c, "go"), dt))
         tol = dict(rtol=2e-2, atol=2e-2) if dt == "bf16" else dict(rtol=1e-4, atol=1e-5)
         for name, got in (("out", out), ("gw", lin.weight.grad), ("gx", x.grad)):

@@ -293,3 +293,31 @@ def test_export_8bit_bf16_plus_128_is_counted_not_hidden():
     assert over[0] == int((idx > 127).sum())
     b16, _, o16 = O.export("sym", xb_np, 1, 16, 8, "int16", "bf16")
     assert o16[0] == 0 and (O.unpack_bins(b16, 16, "int16", True) == idx.reshape(1, 16)).all()
+
+
+def test_module_level_operands_match_the_oracle():
+    """quantize_linear.npz (round 4: + `opx` / `opw`, the tensors the real reference's QuantizeLinear hands to F.linear,
+    models/utils_quant.py:195-250): the oracle reproduces them bit for bit -- W >= 3 weights and Sym / Asym activations, per row and
+    layerwise, fp32 and bf16 -- so the module's OPERANDS are pinned at module level, not only its GEMM outputs (which depend on the
+    accumulation order and are compared with a tolerance)."""
+    G = golden("quantize_linear.npz")
+    checked = 0
+    for c in G.cases:
+        dt = c["dtype"]
+        w, x = G.arr(c, "w"), G.arr(c, "x")
+        if 3 <= c["w_bits"] < 32:
+            rows, cols = O.rows_cols(w.shape, c.get("weight_layerwise", False))
+            y, _, _ = O.sym_fwd(w, rows, cols, c["w_bits"], dt, want_idx=False)
+            assert bits_equal(y.reshape(w.shape), G.arr(c, "opw"), dt), f"{c['name']}: weight operand"
+            checked += 1
+        elif c["w_bits"] >= 32:
+            assert bits_equal(w, G.arr(c, "opw"), dt), c["name"]
+        if 2 < c["a_bits"] < 32:
+            rows, cols = O.rows_cols(x.shape, c.get("act_layerwise", False))
+            fn = O.sym_fwd if c["symmetric"] else O.asym_fwd
+            y = fn(x, rows, cols, c["a_bits"], dt, want_idx=False)[0]
+            assert bits_equal(y.reshape(x.shape), G.arr(c, "opx"), dt), f"{c['name']}: input operand"
+            checked += 1
+        else:
+            assert bits_equal(x, G.arr(c, "opx"), dt), c["name"]   # a_bits <= 2 or >= 32: the input goes in as it is (:184, :244)
+    assert checked >= 30

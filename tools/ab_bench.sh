@@ -1,19 +1,18 @@
 #!/bin/bash
 # A/B two builds of the library on the SAME box (box-to-box variance is 3-5 %): alternate them, ROUNDS times each, through
 # `bench.py --model-shapes`, then print per-entry medians.   tools/ab_bench.sh <libA.so> <libB.so> [rounds] [outdir]
+# The loader is pointed at each variant through LLMQAT_AMD_LIB: the product library is never overwritten (round 3's
+# version copied the variants over it and restored it only if every run succeeded).
 set -eu
-A=$1; B=$2; ROUNDS=${3:-2}; OUT=${4:-gpurun_out/ab}
+A=$(readlink -f "$1"); B=$(readlink -f "$2"); ROUNDS=${3:-2}; OUT=${4:-gpurun_out/ab}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-LIB=$ROOT/llm-qat_amd/libllmqat_fakequant.so
-mkdir -p "$OUT"; cp "$LIB" "$OUT/product.so.keep"; cp "$A" "$OUT/A.so"; cp "$B" "$OUT/B.so"; A=$OUT/A.so; B=$OUT/B.so
+mkdir -p "$OUT"
 for r in $(seq 1 "$ROUNDS"); do
   for v in A B; do
     src=$A; [ $v = B ] && src=$B
-    cp "$src" "$LIB"
-    timeout -k 10 240 python3 "$ROOT/bench.py" --model-shapes --steps 40 > "$OUT/$v$r.json" 2> "$OUT/$v$r.err"
+    LLMQAT_AMD_LIB="$src" timeout -k 10 400 python3 "$ROOT/bench.py" --model-shapes --steps 40 > "$OUT/$v$r.json" 2> "$OUT/$v$r.err"
   done
 done
-cp "$OUT/product.so.keep" "$LIB"; rm -f "$OUT/A.so" "$OUT/B.so" "$OUT/product.so.keep"
 python3 - "$OUT" "$ROUNDS" <<'PY'
 import json, sys, statistics
 out, rounds = sys.argv[1], int(sys.argv[2])

@@ -19,7 +19,6 @@ import weakref
 
 import torch
 import torch.nn as nn
-from torch.autograd.function import once_differentiable
 
 from . import compiled, cpu_tensors, ops
 
@@ -82,6 +81,28 @@ def stats(reset=False):
     if reset:
         _stats.clear()
     return out
+
+
+def _graph_aware(backward):
+    """For every backward below (they launch kernels, which autograd cannot look into).  The reference's backward is made of
+    differentiable ops (`grad_output.clone()` + two masked assignments, :83-87), so `create_graph=True` works there; rounds 1-3
+    answered it with @once_differentiable's error.  The op is `keep * g` with a mask that does not depend on g, so when a graph is
+    asked for -- grad mode is ON inside backward -- the kernels run once on ONES to learn what they keep, and `torch.where` applies
+    that to the real gradients: the same values (a masked NaN becomes 0, as with the masked assignment), differentiable in g to any
+    order, at the cost of one extra launch and two ATen ops in that rare mode only.  Without a graph the kernels run as before."""
+    def wrapper(ctx, *grads):
+        if not torch.is_grad_enabled():
+            return backward(ctx, *grads)
+        with torch.no_grad():
+            keeps = backward(ctx, *[None if g is None else torch.ones_like(g) for g in grads])
+        outs = list(keeps)
+        for i, g in enumerate(grads):
+            k = keeps[i]
+            if g is None or k is None:
+                continue
+            outs[i] = torch.where(k != 0, g if g.dtype == k.dtype else g.to(k.dtype), torch.zeros((), dtype=k.dtype, device=k.device))
+        return tuple(outs)
+    return wrapper
 
 
 class _FakeQuantFunction(torch.autograd.Function):
@@ -155,7 +176,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable  # the backward launches kernels: a double backward must fail loudly, not return silent zeros
+    @_graph_aware
     def backward(ctx, grad_output):
         if ctx.fq_mode == "compiled":
             input, clip_val = ctx.saved_tensors
@@ -342,7 +363,7 @@ def _calibrate_grad_counts():
             return w * 1.0, x * 1.0
 
         @staticmethod
-        @once_differentiable
+        @_graph_aware
         def backward(ctx, gw, gx):
             _ref_base["named"] = _grad_counts(gw)
             return gw, gx
@@ -524,7 +545,7 @@ class _PairNode(torch.autograd.Function):
         return wq, xq
 
     @staticmethod
-    @once_differentiable
+    @_graph_aware
     def backward(ctx, gw, gx):
         inplace_w = ctx.inplace_w and _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
         _backward_started()
@@ -703,7 +724,7 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
         return y.view_as(y)
 
     @staticmethod
-    @once_differentiable
+    @_graph_aware
     def backward(ctx, grad_output):
         inplace = _INPLACE_WGRAD and _inplace_ok(grad_output)
         lo, hi = ctx.clip
@@ -727,7 +748,7 @@ class _PrecomputedAct(torch.autograd.Function):
         return y.view_as(y)
 
     @staticmethod
-    @once_differentiable
+    @_graph_aware
     def backward(ctx, grad_output):
         _backward_started()
         (side,) = ctx.saved_tensors

@@ -880,19 +880,50 @@ def test_torch_compile_traces_through_the_quantizers(pkg, autocast):
     dynamo.reset()
 
 
-def test_double_backward_fails_loudly(pkg):
-    """The reference's backward is built from differentiable ATen ops; this one launches kernels.  Asking for a second
-    derivative through it must raise instead of silently returning nothing."""
-    from llm_qat_amd.utils_quant import SymQuantizer
-    x = torch.randn(8, 256, device="cuda", requires_grad=True)
-    y = SymQuantizer.apply(x, torch.tensor([-2.0, 2.0]), 8, False)
-    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
-    with pytest.raises(RuntimeError):   # no graph behind gx (or once_differentiable's error when grad_output itself carries one)
-        gx.sum().backward()
-    g = torch.ones_like(y, requires_grad=True)
-    (gx,) = torch.autograd.grad(y, x, grad_outputs=g, create_graph=True)
-    with pytest.raises(RuntimeError, match="once_differentiable"):
-        gx.sum().backward()
+def test_double_backward_matches_the_reference(pkg):
+    """VERDICT r03 "missing" item 4: the reference's backward is built from differentiable ATen ops (utils_quant.py:83-87), so
+    `create_graph=True` works there.  The drop-in's backward launches kernels; asked for a graph it re-expresses the same values as
+    `where(keep, g, 0)` with the mask learned from one extra launch on ones -- first and second derivatives equal the eager chain's,
+    through SymQuantizer / AsymQuantizer in every backward data flow, through QuantizeLinear (pair node, in-place path never taken),
+    and under autocast (fp32 gradient in, 16-bit gradient out)."""
+    from llm_qat_amd.utils_quant import AsymQuantizer, QuantizeLinear, SymQuantizer
+    from oracle import eager_chain as E
+    clip = torch.tensor([-2.0, 2.0])
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    prev = pkg.get_backward_mode()
+    pkg.set_semantics("device_eager")
+    try:
+        for mode in ("mask", "bounds", "plain"):
+            pkg.set_backward_mode(mode)
+            for ours, ref in ((SymQuantizer, E.EagerSym), (AsymQuantizer, E.EagerAsym)):
+                for dt, ac in ((torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)):
+                    x0 = (torch.randn(8, 256, generator=gen, device="cuda") * 1.5).to(dt)
+                    g0 = torch.randn(8, 256, generator=gen, device="cuda")
+                    res = []
+                    for q in (ours, ref):
+                        x = x0.clone().requires_grad_(True)
+                        g = g0.clone().requires_grad_(True)
+                        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+                            y = q.apply(x, clip, 8, False)
+                        (gx,) = torch.autograd.grad(y, x, grad_outputs=g.to(y.dtype), create_graph=True)
+                        assert gx.requires_grad
+                        # a second-order quantity: d/dg of sum(gx^2) = 2 * keep * gx
+                        (gg,) = torch.autograd.grad(gx.float().square().sum(), g)
+                        res.append((y.detach(), gx.detach(), gg))
+                    for a, b in zip(res[0], res[1]):
+                        assert a.dtype == b.dtype and torch.equal(a, b), (mode, ours.__name__, dt, ac)
+                    assert int((res[0][1] == 0).sum()) > 0
+        pkg.set_backward_mode("mask")
+        lin = QuantizeLinear(256, 64, w_bits=4, a_bits=8).cuda()
+        x = torch.randn(16, 256, device="cuda", requires_grad=True)
+        out = lin(x)
+        gx, gw = torch.autograd.grad(out.square().sum(), (x, lin.weight), create_graph=True)
+        pkg.stats(reset=True)
+        (gx.square().sum() + gw.square().sum()).backward()      # flows through F.linear's double backward and the fake-quant masks
+        assert lin.weight.grad is not None and x.grad is not None and torch.isfinite(x.grad).all()
+    finally:
+        pkg.set_backward_mode(prev)
+        pkg.set_semantics("cpu_eager")
 
 
 # ------------------------------------------------------------------------------------------ saved tensors (VERDICT r01 item 6)

@@ -17,7 +17,9 @@
  *         ndim == 4 : rows = d0*d1, cols = d2*d3                    (utils_quant.py:60-68)
  *         layerwise : rows = 1, cols = numel                        (utils_quant.py:50-51)
  *   - return value: 0 on success, negative FQ_ERR_* otherwise; fq_last_error() gives a
- *     thread-local message.  Nothing throws across the boundary.
+ *     thread-local message.  Nothing throws across the boundary.  FQ_ERR_LAUNCH is the status hipLaunchKernel() RETURNED for this
+ *     call's own launches: the library neither reads nor clears the thread's hipGetLastError() slot, so an error another library
+ *     left pending there is not hidden, and not mistaken for this library's.
  *   - stateless and re-entrant: safe from the autograd thread, under
  *     torch.utils.checkpoint recompute and inside DDP/FSDP hooks.
  *   - arithmetic: bit-exact replay of the reference's op-by-op rounding in the tensor
@@ -35,7 +37,7 @@ extern "C" {
 
 #define FQ_ABI_VERSION 4 /* 2: + multi-tensor launches, export, row scales, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap;
                             4: fq_sym_fwd_autocast takes `sem` (and the autocast modes of pair / multi / export / row_scales honour it),
-                               FQ_ERR_PENDING, fq_qlinear_fwd (an experiment with test hooks in its signature) left the library, fq_w12_fwd_rows sums
+                               launch status from hipLaunchKernel's return value (the hipGetLastError slot is left alone), fq_qlinear_fwd (an experiment with test hooks in its signature) left the library, fq_w12_fwd_rows sums
                                in ATen's own order (no `sem`) */
 
 /* element types */
@@ -64,8 +66,6 @@ extern "C" {
 #define FQ_ERR_LAUNCH (-6)
 #define FQ_ERR_ARG (-7)
 #define FQ_ERR_UNSUPPORTED (-8) /* shape/alignment not served by this entry point: use the general one */
-#define FQ_ERR_PENDING (-9)     /* a HIP error raised by an EARLIER launch / another library was pending on this thread: nothing was
-                                   launched, the error is left in place (hipGetLastError() still returns it to its owner) */
 
 int fq_version(void);               /* == FQ_ABI_VERSION */
 const char* fq_build_info(void);    /* e.g. "llmqat_fakequant abi 1, gfx950, hip 7.2" */

@@ -37,7 +37,6 @@ class BwdTensor(ctypes.Structure):  # fq_bwd_tensor
 
 BINS_NONE, BINS_INT4, BINS_INT8, BINS_INT16 = 0, 1, 2, 3
 ERR_UNSUPPORTED = -8
-ERR_PENDING = -9
 
 _lock = threading.Lock()
 _lib = None
@@ -131,6 +130,4 @@ def check(rc, what):
         msg = lib().fq_last_error().decode(errors="replace")
         if rc in (-2,):  # FQ_ERR_BITS
             raise ValueError(f"{what}: {msg}")
-        if rc == ERR_PENDING:
-            raise RuntimeError(f"{what}: not launched -- {msg}")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

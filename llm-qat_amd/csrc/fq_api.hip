@@ -28,6 +28,10 @@ int ok() {
     g_err[0] = 0;
     return FQ_OK;
 }
+hipError_t& launch_status() {
+    static thread_local hipError_t st = hipSuccess;
+    return st;
+}
 }  // namespace fq
 
 namespace {

@@ -6,7 +6,7 @@
 
 namespace fq {
 
-#define FQ_LAUNCH(kern, grid, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, st, __VA_ARGS__)
+#define FQ_LAUNCH(kern, grid, block, st, ...) FQ_LAUNCHK(kern, dim3((unsigned)(grid)), dim3(block), 0, st, __VA_ARGS__)
 
 // Which (threads per row, 16-byte vectors per thread) the model widths select (bf16 / fp16: 8 elements per vector):
 //   4096 -> 512 vectors -> 256 x 2     5120 -> 640 -> 256 x 3     11008 -> 1376 -> 512 x 3     13824 -> 1728 -> 512 x 4
@@ -80,7 +80,7 @@ static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
 template <int DT, int AC>
 static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     seal_slots(a);
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors only");
@@ -155,7 +155,7 @@ template <int DT> int launch_sym_autocast(bool wide, RowArgs a, void* ws, size_t
 template <int DT, bool ASYM, bool FAST>
 static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     seal_slots(a);
     constexpr int EPV = 16 / T::ESIZE;
     const bool pair = a.n_more > 0;  // several tensors in one launch: register kernels only
@@ -218,7 +218,7 @@ template <int DT> int launch_rowwise(bool asym, bool fast, RowArgs a, void* ws, 
 
 template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     constexpr int EPV = 16 / T::ESIZE;
     if (aligned16(g) && aligned16(x) && aligned16(gx) && n % EPV == 0) {
         const int64_t nvec = n / EPV;
@@ -241,7 +241,7 @@ template <int DT>
 int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
                     hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     constexpr int EPV = 16 / T::ESIZE;
     if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0))
         return launch_ste<DT>(g, x, gx, rows * cols, lo, hi, st);  // odd layout: plain path, same result
@@ -279,11 +279,11 @@ inline int64_t ste_layout(SteLaunch& L, bool allow_inplace) {
     }
     return blk;
 }
-#define FQ_LAUNCH2(kern, gx_, gy_, block, st, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(gx_), (unsigned)(gy_)), dim3(block), 0, st, __VA_ARGS__)
+#define FQ_LAUNCH2(kern, gx_, gy_, block, st, ...) FQ_LAUNCHK(kern, dim3((unsigned)(gx_), (unsigned)(gy_)), dim3(block), 0, st, __VA_ARGS__)
 
 template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     constexpr int EPV = 16 / T::ESIZE;
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape not served");
@@ -314,7 +314,7 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
 
 template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, float hi, hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     if constexpr (T::ESIZE != 2) {
         return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward applies to bf16 / fp16 inputs only");
     } else {
@@ -347,7 +347,7 @@ template <int DT>
 int launch_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, float cv,
                hipStream_t st) {
     using T = Ty<DT>;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     constexpr int EPV = 16 / T::ESIZE;
     const bool vec = aligned16(w) && aligned16(out) && cols % EPV == 0;
     int64_t grid = vec ? (rows * (cols / EPV) + 255) / 256 : (rows * cols + 255) / 256;
@@ -377,7 +377,7 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
     constexpr int MAXG_OWN = DT == F32 ? 16 : 32;              // fp32 groups are 4 VGPRs each
     if (gpt > (shared_row ? 16 : MAXG_OWN) || (shared_row && (cols + 511) / 512 >= 256))
         return fail(FQ_ERR_UNSUPPORTED, "one-launch 1-/2-bit branch: cols=%lld outside the row lengths this kernel holds in registers", (long long)cols);
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     const float factor = (float)rows / (float)(rows * cols);   // ATen: static_cast<float>(num_outputs) / numel
     const bool ntl = rows * cols * T::ESIZE >= NT_LOAD_MIN_BYTES;
     const int64_t grid = shared_row ? rows : (rows + 7) / 8;

@@ -14,7 +14,7 @@ namespace {
 template <int DT, bool ASYM, bool NTL> void launch_export_reg(const ExportArgs& a, int64_t nvec, hipStream_t st) {
 #define R(TPR, V)                                                                                                              \
     case V:                                                                                                                    \
-        hipLaunchKernelGGL((row_export_kernel<DT, TPR, V, ASYM, NTL>), dim3((unsigned)(TPR == 64 ? (a.rows + 3) / 4 : a.rows)), \
+        FQ_LAUNCHK((row_export_kernel<DT, TPR, V, ASYM, NTL>), dim3((unsigned)(TPR == 64 ? (a.rows + 3) / 4 : a.rows)), \
                            dim3(TPR == 64 ? 256 : TPR), 0, st, a);                                                             \
         break;
     // launch shapes of the forward kernel (fq_dtype_impl.h launch_reg): same loads, same reduction
@@ -35,7 +35,7 @@ template <int DT, bool ASYM, bool NTL> void launch_export_reg(const ExportArgs& 
 template <int DT, bool ASYM> int export_t(const ExportArgs& a, hipStream_t st) {
     using T = Ty<DT>;
     constexpr int EPV = 16 / T::ESIZE;
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
     const int64_t nvec = a.cols / EPV;
     // packed stores need the bins row to start on the store's natural boundary: EPV elements -> EPV*cbits/8 bytes
@@ -47,7 +47,7 @@ template <int DT, bool ASYM> int export_t(const ExportArgs& a, hipStream_t st) {
         else launch_export_reg<DT, ASYM, false>(a, nvec, st);
     } else {
         if (a.mask) return fail(FQ_ERR_UNSUPPORTED, "STE mask: rows must be 16-byte aligned and fit the register kernels (see fq_ste_mask_bytes)");
-        hipLaunchKernelGGL((row_export_generic_kernel<DT, ASYM>), dim3((unsigned)a.rows), dim3(256), 0, st, a);
+        FQ_LAUNCHK((row_export_generic_kernel<DT, ASYM>), dim3((unsigned)a.rows), dim3(256), 0, st, a);
     }
     return launch_result();
 }

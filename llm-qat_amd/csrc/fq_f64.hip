@@ -130,34 +130,34 @@ __global__ __launch_bounds__(256) void w12_f64_kernel(const double* __restrict__
 }
 
 int launch_f64_rowwise(bool asym, const void* x, void* y, int32_t* idx, float* scale, int64_t rows, int64_t cols, int bits, int sem, hipStream_t st) {
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     if (rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)rows);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 7u) return fail(FQ_ERR_UNSUPPORTED, "float64 tensors must be 8-byte aligned");
     if (asym) {
         const double S = (double)((1ull << bits) - 1ull);
-        hipLaunchKernelGGL(row_f64_kernel<true>, dim3((unsigned)rows), dim3(F64_THREADS), 0, st, (const double*)x, (double*)y, idx, scale, cols, S,
+        FQ_LAUNCHK(row_f64_kernel<true>, dim3((unsigned)rows), dim3(F64_THREADS), 0, st, (const double*)x, (double*)y, idx, scale, cols, S,
                            sem == FQ_SEM_DEVICE_EAGER ? 1 : 0);
     } else {
         const double qmax = (double)((1u << (bits - 1)) - 1u);
-        hipLaunchKernelGGL(row_f64_kernel<false>, dim3((unsigned)rows), dim3(F64_THREADS), 0, st, (const double*)x, (double*)y, idx, scale, cols, qmax, 0);
+        FQ_LAUNCHK(row_f64_kernel<false>, dim3((unsigned)rows), dim3(F64_THREADS), 0, st, (const double*)x, (double*)y, idx, scale, cols, qmax, 0);
     }
     return launch_result();
 }
 
 int launch_f64_ste(const void* g, const void* x, void* gx, int64_t n, float lo, float hi, hipStream_t st) {
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     int64_t grid = (n + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(ste_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const double*)g, (const double*)x, (double*)gx, n, (double)lo, (double)hi);
+    FQ_LAUNCHK(ste_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const double*)g, (const double*)x, (double*)gx, n, (double)lo, (double)hi);
     return launch_result();
 }
 
 int launch_f64_w12(const void* w, const void* scale, void* out, int64_t rows, int64_t cols, int w_bits, int scale_per_row, hipStream_t st) {
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     int64_t grid = (rows * cols + 255) / 256;
     if (grid > 16384) grid = 16384;
-    if (w_bits == 1) hipLaunchKernelGGL(w12_f64_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, (const double*)w, (const double*)scale, (double*)out, rows, cols, scale_per_row);
-    else hipLaunchKernelGGL(w12_f64_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (const double*)w, (const double*)scale, (double*)out, rows, cols, scale_per_row);
+    if (w_bits == 1) FQ_LAUNCHK(w12_f64_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, (const double*)w, (const double*)scale, (double*)out, rows, cols, scale_per_row);
+    else FQ_LAUNCHK(w12_f64_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (const double*)w, (const double*)scale, (double*)out, rows, cols, scale_per_row);
     return launch_result();
 }
 

@@ -4,6 +4,8 @@
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <tuple>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -19,21 +21,31 @@ namespace fq {
 FQ_HIDDEN int fail(int code, const char* fmt, ...);
 FQ_HIDDEN int ok();
 
-// hipLaunchKernelGGL returns nothing, and hipGetLastError() reports the calling thread's LAST error, whoever caused it.  A
-// launch function therefore PEEKS first: an error that is already pending belongs to an earlier launch or to another
-// library, so it is reported as such (FQ_ERR_PENDING), left in place for its owner to see, and nothing is launched on top of
-// a context in an unknown state.  (Rounds 1-3 drained it silently: that hid other people's failures.)  With nothing pending,
-// whatever hipGetLastError() returns after the launches is this call's own.
-inline int pending_error() {
-    const hipError_t e = hipPeekAtLastError();
-    return e == hipSuccess ? 0
-                           : fail(FQ_ERR_PENDING, "a HIP error was already pending on this thread before this call (an earlier launch or another "
-                                  "library raised it; it is not cleared here): %s", hipGetErrorString(e));
+// Launch status.  hipLaunchKernelGGL returns nothing, and hipGetLastError() reports -- and clears -- the calling thread's LAST error,
+// whoever caused it: rounds 1-3 drained that slot before every launch (hiding other libraries' failures) and read it afterwards.
+// Since round 4 the library never touches the slot: every kernel goes through hipLaunchKernel(), whose RETURN VALUE is the status of
+// that launch alone; the first failure of an entry point's launches is kept (per thread) and reported by launch_result().  A HIP
+// error that an earlier launch or another library left pending is neither cleared nor mistaken for ours.
+FQ_HIDDEN hipError_t& launch_status();   // thread-local, defined in fq_api.hip
+inline void begin_launches() { launch_status() = hipSuccess; }
+template <typename... P, size_t... I>
+inline hipError_t launch_with(void (*kernel)(P...), dim3 grid, dim3 block, hipStream_t st, std::tuple<P...>& params, std::index_sequence<I...>) {
+    void* args[] = {(void*)&std::get<I>(params)...};
+    return hipLaunchKernel((const void*)kernel, grid, block, args, 0, st);
+}
+// arguments are converted to the kernel's own parameter types first (hipLaunchKernel takes them by address)
+template <typename... P, typename... A> inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, hipStream_t st, A&&... a) {
+    static_assert(sizeof...(P) == sizeof...(A), "argument count does not match the kernel's parameter list");
+    std::tuple<P...> params{static_cast<P>(std::forward<A>(a))...};
+    const hipError_t e = launch_with(kernel, grid, block, st, params, std::index_sequence_for<P...>{});
+    if (e != hipSuccess && launch_status() == hipSuccess) launch_status() = e;
 }
 inline int launch_result() {
-    const hipError_t e = hipGetLastError();
+    const hipError_t e = launch_status();
     return e == hipSuccess ? ok() : fail(FQ_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
 }
+// (drop-in for the hipLaunchKernelGGL call shape; the kernels use no dynamic LDS)
+#define FQ_LAUNCHK(kern, grid, block, shmem, st, ...) ::fq::launch(kern, grid, block, st, __VA_ARGS__)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 // the further tensors of a multi-tensor launch: alignment of their x / y, and the rows of the largest tensor (its size

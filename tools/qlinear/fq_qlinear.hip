@@ -48,6 +48,10 @@ int ok() {
     g_qerr[0] = 0;
     return FQ_OK;
 }
+hipError_t& launch_status() {
+    static thread_local hipError_t st = hipSuccess;
+    return st;
+}
 }  // namespace fq
 
 namespace {
@@ -268,10 +272,10 @@ __global__ __launch_bounds__(QL_THREADS, 2) void qlinear_kernel(QLArgs a) {
 template <int QA, int QW> int launch_ql(const QLArgs& a, int ablation, hipStream_t st) {
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(QL_THREADS);
     const bool dump = a.dump_x || a.dump_w;
-    if (ablation == 1) hipLaunchKernelGGL((qlinear_kernel<QA, QW, false, 1>), grid, block, 0, st, a);
-    else if (ablation == 2) hipLaunchKernelGGL((qlinear_kernel<QA, QW, false, 2>), grid, block, 0, st, a);
-    else if (dump) hipLaunchKernelGGL((qlinear_kernel<QA, QW, true, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((qlinear_kernel<QA, QW, false, 0>), grid, block, 0, st, a);
+    if (ablation == 1) FQ_LAUNCHK((qlinear_kernel<QA, QW, false, 1>), grid, block, 0, st, a);
+    else if (ablation == 2) FQ_LAUNCHK((qlinear_kernel<QA, QW, false, 2>), grid, block, 0, st, a);
+    else if (dump) FQ_LAUNCHK((qlinear_kernel<QA, QW, true, 0>), grid, block, 0, st, a);
+    else FQ_LAUNCHK((qlinear_kernel<QA, QW, false, 0>), grid, block, 0, st, a);
     return launch_result();
 }
 
@@ -316,7 +320,7 @@ FQ_API int fq_qlinear_fwd(const void* x, const float* x_scales, const void* w, c
     a.tiles_m = (int)((tokens + QL_BM - 1) / QL_BM);
     a.tiles_n = (int)((out_features + QL_BN - 1) / QL_BN);
     if ((int64_t)a.tiles_m * a.tiles_n > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "too many tiles");
-    if (const int pending = pending_error()) return pending;
+    begin_launches();
     hipStream_t st = (hipStream_t)stream;
     const int q = autocast ? 2 : 1;
     const int qa = x_scales ? q : 0, qw = w_scales ? q : 0;

@@ -76,7 +76,7 @@ def stats(reset=False):
       wcache_fill / wcache_hit           weight-quant cache (opt-in)
       inplace_taken / inplace_refused:<reason>
                                          weight gradients masked where they stand vs copied, by the guard's reason
-                                         (uncalibrated, disabled, storage, anomaly, py_refs, cxx_refs, storage_refs, base_refs)"""
+                                         (uncalibrated, storage, anomaly, py_refs, cxx_refs, storage_refs, base_refs)"""
     out = dict(_stats)
     if reset:
         _stats.clear()

@@ -11,6 +11,9 @@ int fqo_sym_fwd(const void*, void*, int32_t*, float*, int64_t, int64_t, int, int
 int fqo_asym_fwd(const void*, void*, int32_t*, float*, float*, int64_t, int64_t, int, int, int);
 int fqo_ste_bwd(const void*, const void*, void*, int64_t, float, float, int);
 int fqo_w12_fwd(const void*, void*, float*, const float*, int64_t, int64_t, int, int);
+int fqo_sym_fwd_autocast(const void*, void*, int32_t*, float*, int64_t, int64_t, int, int, int, int);
+int fqo_ste_bwd_wide(const float*, const void*, void*, int64_t, float, float, int);
+int fqo_export(const void*, void*, float*, int32_t*, int64_t, int64_t, int, int, int, int, int, int);
 
 static uint32_t rng = 12345u;
 static uint32_t next(void) { rng = rng * 1664525u + 1013904223u; return rng; }
@@ -41,6 +44,22 @@ int main(void) {
                 }
             }
             if (fqo_ste_bwd(g, x, gx, n, -2.f, 2.f, dt) || fqo_ste_bwd(g, x, gx, n, -0.3009f, 0.75f, dt)) return 5;
+            if (dt != 0) {   /* the autocast arithmetic (16-bit tensors): fp32 and narrow results, both scalar policies; the fp32-gradient backward; export */
+                float* y32 = malloc(n * 4 + 1), *g32 = malloc(n * 4 + 1), *sc2 = malloc(rows * 8 + 1);
+                int32_t* ov = malloc(rows * 4 + 1);
+                uint8_t* bins = malloc(n * 2 + 1);
+                for (int64_t i = 0; i < n; ++i) g32[i] = (next() % 9 == 0) ? specials[next() % (sizeof specials / sizeof specials[0])] : ((int32_t)next() / 1.0e9f);
+                for (int bits = 2; bits <= 31; bits += (bits < 8 ? 2 : 7))
+                    for (int sem = 0; sem < 2; ++sem) {
+                        if (fqo_sym_fwd_autocast(x, y32, idx, s, rows, cols, bits, dt, 1, sem) || fqo_sym_fwd_autocast(x, y, NULL, NULL, rows, cols, bits, dt, 0, sem)) return 9;
+                        for (int cont = 1; cont <= 3; ++cont)
+                            if (fqo_export(x, bins, sc2, ov, rows, cols, bits, cont, dt, sem, 0, 1)) return 10;
+                        calls += 5;
+                    }
+                if (fqo_ste_bwd_wide(g32, x, gx, n, -2.f, 2.f, dt)) return 11;
+                ++calls;
+                free(y32); free(g32); free(sc2); free(ov); free(bins);
+            }
             if (cols > 0) {
                 if (fqo_w12_fwd(x, y, s, NULL, rows, cols, 1, dt) || fqo_w12_fwd(x, y, s, NULL, rows, cols, 2, dt)) return 6;
                 if (fqo_w12_fwd(x, y, s2, s, rows, cols, 2, dt)) return 7;

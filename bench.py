@@ -28,6 +28,8 @@ Families (every `frac` is a byte RATE the kernel sustained / 8 TB/s, never > 1):
   roofline      dominant kernel (the step's forward launch): algorithmic bytes / live HIP-event launch time vs 8 TB/s
   kernels_step  both launches of the step;  kernels  the four single-tensor launches
   kernels_model_shapes   the quantizer launches of one LLaMA-7B layer at their real shapes
+  sustained     the headline step back to back for --sustain-seconds (default 5 s) after the timed region: the steady-state rate, and
+                long enough for an outside utilisation sampler (the driver's gpu_busy, rocm-smi) to see the GPU at work
   autograd_path the same step through SymQuantizer.apply / backward (allocator + Python included)
   cpu_baseline  the reference's CPU path (eager op chain, oracle/eager_chain.py) timed on this box's host
                 cores on a bounded sample -- rank 0, N=1 only
@@ -81,6 +83,28 @@ def timed_region(step, steps, warmup, sync, dist_mod=None):
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def sustained_region(step, seconds, sync, chunk=1000, clock=time.perf_counter):
+    """The same step back to back for about `seconds` of wall time, in chunks of `chunk` steps with one device sync per chunk (the
+    queue never drains inside a chunk).  NOT the headline -- K stays exactly --steps -- but it answers two things the 2-25 ms timed
+    region cannot: whether the rate holds once clocks and temperatures settle, and it keeps the GPU busy for long enough that an
+    outside observer's utilisation sampling (the driver's `gpu_busy`, rocm-smi) sees this process at all.
+    Returns (steps_run, seconds_run, [ms_per_step of each chunk])."""
+    if seconds <= 0:
+        return 0, 0.0, []
+    sync()
+    chunks, n, t_start = [], 0, clock()
+    while True:
+        t0 = clock()
+        for i in range(chunk):
+            step(n + i)
+        sync()
+        t1 = clock()
+        chunks.append((t1 - t0) / chunk * 1e3)
+        n += chunk
+        if t1 - t_start >= seconds:
+            return n, t1 - t_start, chunks
 
 
 def aggregate_value(elems_per_rank_step, steps, world, seconds):
@@ -803,6 +827,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="after the timed region: run the same step back to back for this long and report the rate (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip per-kernel / eager measurements")
     ap.add_argument("--core-extras", action="store_true",
                     help="per-kernel entries of the step's own kernels only (no model shapes / export / fused GEMM / eager / CPU): what "
@@ -973,6 +999,9 @@ def main(argv=None):
     seconds_pd = timed_region(wl.step, args.steps, args.warmup, torch.cuda.synchronize, dist)
     elems_step = 2 * wl.n
     value = aggregate_value(elems_step, args.steps, world, seconds)
+    sus_steps, sus_s, sus_chunks = sustained_region(wl.step_out_of_place, 0.0 if args.no_extras else args.sustain_seconds, torch.cuda.synchronize)
+    if sus_steps:
+        PROFILE_MANIFEST.append(("sustained: step (both gradients written)", 2 * sus_steps))
     ms_step = seconds / args.steps * 1e3
     ms_step_pd = seconds_pd / args.steps * 1e3
     clip_frac = wl.clippable_fraction()
@@ -1007,6 +1036,13 @@ def main(argv=None):
         "hbm_gbs_note": "bytes the step's two launches move (fwd 4 + bwd 4 B/elem + mask bits) / ms_per_step: a real byte rate",
     }
     out.update(info)
+    if sus_steps:
+        cs = sorted(sus_chunks)
+        out["sustained"] = {"value": round(elems_step * sus_steps / sus_s / 1e9, 2), "unit": "Gelem/s", "seconds": round(sus_s, 2), "steps": sus_steps,
+                            "ms_per_step_min_median_max": [round(cs[0], 4), round(cs[len(cs) // 2], 4), round(cs[-1], 4)],
+                            "ms_per_step_first_last_chunk": [round(sus_chunks[0], 4), round(sus_chunks[-1], 4)],
+                            "what": "rank 0, the headline step back to back for `seconds` (1000-step chunks, one sync each), after the timed "
+                                    "region: steady-state rate per GPU; not the headline"}
 
     if rank == 0 and not args.no_extras:
         traffic, tsrc = load_traffic()
@@ -1157,6 +1193,9 @@ def compact_headline(out, extras_file=None):
     ap = out.get("api_path")
     if ap:
         h["api_path_gelem_s"] = ap.get("value")
+    su = out.get("sustained")
+    if su:
+        h["sustained_gelem_s"], h["sustained_seconds"] = su["value"], su["seconds"]
     sc = self_check(out)
     if sc:
         h["self_check"] = sc
@@ -1169,7 +1208,7 @@ def compact_headline(out, extras_file=None):
         h["extras"] = extras_file
     line = json.dumps(h)
     if len(line.encode()) >= HEADLINE_MAX_BYTES:   # cannot happen with the clips above; if it ever does, shed the optional parts, never the contract
-        for k in ("gpu_eager_gelem_s", "speedup_vs_gpu_eager", "api_path_gelem_s", "extras", "self_check", "roofline_step", "cpu_baseline"):
+        for k in ("gpu_eager_gelem_s", "speedup_vs_gpu_eager", "api_path_gelem_s", "sustained_gelem_s", "sustained_seconds", "extras", "self_check", "roofline_step", "cpu_baseline"):
             h.pop(k, None)
             line = json.dumps(h)
             if len(line.encode()) < HEADLINE_MAX_BYTES:

@@ -19,6 +19,19 @@ def test_timed_region_counts_exactly_k_steps():
     assert calls == list(range(10)) and dt >= 0
 
 
+def test_sustained_region_runs_whole_chunks_until_the_clock_says_so():
+    calls, now = [], [0.0]
+
+    def step(i):
+        calls.append(i)
+        now[0] += 0.001            # each step "takes" 1 ms of the fake clock
+
+    n, secs, chunks = bench.sustained_region(step, 0.25, lambda: None, chunk=100, clock=lambda: now[0])
+    assert n == 300 and calls == list(range(300)) and len(chunks) == 3          # 0.1, 0.2 < 0.25 <= 0.3
+    assert abs(secs - 0.3) < 1e-9 and all(abs(c - 1.0) < 1e-6 for c in chunks)   # ms per step of each chunk
+    assert bench.sustained_region(step, 0.0, lambda: None) == (0, 0.0, [])       # --sustain-seconds 0 skips it
+
+
 def test_aggregate_value_is_whole_job():
     assert bench.aggregate_value(1e9, 10, 1, 10.0) == 1.0
     assert bench.aggregate_value(1e9, 10, 8, 10.0) == 8.0       # N replicas: N x the elements over the same time

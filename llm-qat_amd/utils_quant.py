@@ -918,16 +918,17 @@ class QuantizeLinear(nn.Linear):
             return self._forward_compiled(input_)
         pair = self._pair_forward(input_)
         if pair is not None:
-            return nn.functional.linear(pair[1], pair[0])
-        _count("single_launch")
-        if self.w_bits >= 32:
-            weight = self.weight
-        elif self.w_bits >= 3:
-            weight = self._quantized_weight()
+            weight, input_ = pair
         else:
-            weight = self._low_bit_weight(self.weight)
-        if 2 < self.a_bits < 32:
-            input_ = _shared_activation(self.act_quantizer, input_, self.a_bits, self.act_layerwise)
+            _count("single_launch")
+            if self.w_bits >= 32:
+                weight = self.weight
+            elif self.w_bits >= 3:
+                weight = self._quantized_weight()
+            else:
+                weight = self._low_bit_weight(self.weight)
+            if 2 < self.a_bits < 32:
+                input_ = _shared_activation(self.act_quantizer, input_, self.a_bits, self.act_layerwise)
         out = nn.functional.linear(input_, weight)
         if self.bias is not None:
             out += self.bias.view(1, -1).expand_as(out)

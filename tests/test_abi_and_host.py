@@ -136,14 +136,27 @@ def test_product_never_imports_the_oracle():
                     assert not re.search(pat, src), (os.path.join(dirpath, f), pat)
 
 
+def test_product_never_reaches_into_tools():
+    """tools/ holds experiments and measurements (the quantize-on-load GEMM, the int8 consumer of the export format): the package
+    neither imports them nor loads their libraries"""
+    pkg = os.path.join(ROOT, "llm-qat_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"libfq_qlinear_exp", r"libfq_int8_epilogue", r"int8_linear", r"tools[/.](qlinear|int8_linear)"):
+                    assert not re.search(pat, src), (os.path.join(dirpath, f), pat)
+
+
 def test_oracle_is_only_reached_from_the_allowed_places():
     """Besides tests/: __graft_entry__ (build() compiles it, smoke() checks against it) and bench.py's cpu_baseline leg
     (cpu_baseline, cpu_c_port, parity_gate) -- nowhere else: no tool, no GPU leg of the benchmark."""
     import ast
-    for f in os.listdir(os.path.join(ROOT, "tools")):
-        if f.endswith(".py"):
-            src = open(os.path.join(ROOT, "tools", f)).read()
-            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dirpath, f)
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     allowed = {"cpu_baseline", "cpu_c_port", "parity_gate"}
     for node in ast.walk(tree):

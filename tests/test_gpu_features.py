@@ -528,6 +528,26 @@ def test_paired_operand_launch_is_transparent(pkg, dtype, autocast):
     assert torch.equal(a, b)
 
 
+def test_a_bias_assigned_afterwards_is_added_on_every_path(pkg):
+    """The constructor never creates a bias (reference :176), but forward adds one if the attribute has been set since (:251-252):
+    the paired launch, the two-call flow and conservative mode all do."""
+    from llm_qat_amd.utils_quant import QuantizeLinear
+    torch.manual_seed(3)
+    lin = QuantizeLinear(512, 256, w_bits=4, a_bits=8).cuda().bfloat16()
+    x = torch.randn(4, 32, 512, device="cuda").bfloat16()
+    with torch.no_grad():
+        plain = lin(x)
+        lin.bias = torch.nn.Parameter(torch.randn(256, device="cuda").bfloat16())
+        want = plain + lin.bias.view(1, -1).expand_as(plain)
+        outs = [lin(x)]
+        pkg.pair_operands(False)
+        try:
+            outs.append(lin(x))
+        finally:
+            pkg.pair_operands(True)
+    assert not torch.equal(want, plain) and all(torch.equal(o, want) for o in outs)
+
+
 @pytest.mark.parametrize("autocast", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_kv_hooks_in_one_launch(pkg, dtype, autocast):

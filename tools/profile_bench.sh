@@ -12,7 +12,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras --no-sidecar"
+# (--sustain-seconds 0: the 5 s steady-state leg would add ~86 000 dispatches of the same two kernels to every trace)
+BENCH="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras --no-sidecar --sustain-seconds 0"
 MS="python3 $ROOT/bench.py --model-shapes --steps 30"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || exit 1
 echo "trace done"

@@ -115,7 +115,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    cmd_step = "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras --no-sidecar"
+    cmd_step = "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --core-extras --no-sidecar --sustain-seconds 0"
     cmd_ms = "python3 bench.py --model-shapes --steps 30"
 
     # 0. rocprofv3 --stats summaries, per kernel name (as rocprofv3 prints them)

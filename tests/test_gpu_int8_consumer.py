@@ -24,8 +24,7 @@ def I8():
     spec = importlib.util.spec_from_file_location("_fq_int8_linear", os.path.join(ROOT, "tools", "int8_linear", "int8_linear.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    if not os.path.exists(mod.LIB):
-        pytest.fail("tools/int8_linear/libfq_int8_epilogue.so is missing: run __graft_entry__.build()")
+    mod.build()   # a fresh checkout: hipcc is on the box (a few seconds); __graft_entry__.build() normally did it already
     return mod
 
 

@@ -426,8 +426,8 @@ _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every
 #    sibling projections.  Gradients are unchanged bit for bit: the STE mask is applied once to the
 #    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum.
 #    A hit requires the very same tensor object at the same version and that no fake-quant backward has run
-#    since (so an output whose graph was already consumed is never handed out again); the remembered output is
-#    released as soon as that input tensor dies (weak reference + callback).
+#    since (so an output whose graph was already consumed is never handed out again); the remembered outputs are
+#    released when the next backward starts, or replaced by the next module that quantizes an activation the same way.
 # 2. Under activation checkpointing every weight is fake-quantized twice per step (first forward, then
 #    the recompute -- reentrant or not) although it has not changed.  With the weight cache on (opt-in:
 #    it keeps one quantized copy per layer alive from the first use until the second), the second use
@@ -472,13 +472,18 @@ def _backward_started():
     """every fake-quant backward calls this first: results remembered before it (shared activations, a pending V of the K/V
     hooks) are never handed out afterwards -- their graphs may already be consumed"""
     _bwd_epoch[0] += 1
-    if _kv_stash:   # (a plain dict keyed by the forward thread: the backward runs on the autograd engine's own thread)
+    if _act_caches:   # what was remembered can never match again (epoch): let go of those outputs -- and of the graphs behind them -- now
+        _act_caches.clear()
+    if _kv_stash:   # (plain dicts keyed by the forward thread: the backward runs on the autograd engine's own thread)
         for tid in list(_kv_stash):
             _kv_discard(tid)
 
 
+_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch)}
+
+
 def _act_lookup(key, x):
-    cache = getattr(_tls, "act", None)
+    cache = _act_caches.get(threading.get_ident())
     ent = cache.get(key) if cache else None
     if ent is not None:
         rin, ver_in, y, ver_out, epoch = ent
@@ -489,11 +494,13 @@ def _act_lookup(key, x):
 
 def _act_store(key, x, y):
     """One entry per key: the next module that quantizes an activation with the same settings -- the next layer's q_proj / gate_proj --
-    replaces it, so at most one fake-quantized activation per key outlives its siblings (until the next forward).  A dead input
-    can never match (`rin() is x` on a dead weak reference is False), so id reuse is harmless."""
-    cache = getattr(_tls, "act", None)
+    replaces it, and the first fake-quant backward that starts drops them all (`_backward_started`), so at most one fake-quantized
+    activation per key outlives its siblings, and none outlives the forward pass.  A dead input can never match (`rin() is x` on a
+    dead weak reference is False), so id reuse is harmless."""
+    tid = threading.get_ident()
+    cache = _act_caches.get(tid)
     if cache is None:
-        cache = _tls.act = {}
+        cache = _act_caches[tid] = {}
     cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch[0])
 
 
@@ -688,9 +695,11 @@ def _kv_hook(x, clip_val, num_bits):
 
 
 def reset_learned_state():
-    """forget what the host logic has learned about call sites (today: K/V signatures that stopped pairing)"""
+    """forget what the host logic has learned about call sites (K/V signatures that stopped pairing) and everything it remembers
+    between calls (a pending V result, the last fake-quantized activations)"""
     _kv_off.clear()
     _kv_stash.clear()
+    _act_caches.clear()
 
 
 def conservative(flag=True):

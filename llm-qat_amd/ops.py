@@ -114,15 +114,28 @@ def _ws_bytes(rows, cols, code):
     return v
 
 
+def _empty_input(what, x, layerwise):
+    """A tensor without elements, as the reference treats it (models/utils_quant.py:50-68 / :110-122; asked of the live reference):
+    a reduction over NOTHING raises what torch raises there -- RuntimeError for the layerwise (whole-tensor) max, and for the 4-D
+    branch's `view(d0, d1, -1)` when d0 * d1 == 0 (the -1 is then ambiguous); IndexError for an empty reduction dimension (the last
+    one; d2 * d3 == 0 in the 4-D branch) -- while zero ROWS of a non-empty last dimension simply give an empty result."""
+    if layerwise:
+        raise RuntimeError(f"{what}: max(): Expected reduction dim to be specified for input.numel() == 0 (layerwise reduction of an empty tensor)")
+    if x.dim() == 4:
+        if x.shape[0] * x.shape[1] == 0:
+            raise RuntimeError(f"{what}: cannot reshape tensor of 0 elements into shape [{x.shape[0]}, {x.shape[1]}, -1] because the unspecified "
+                               "dimension size -1 can be any value and is ambiguous")
+        raise IndexError(f"{what}: max(): Expected reduction dim 2 to have non-zero size.")
+    if x.shape[-1] == 0:
+        raise IndexError(f"{what}: max(): Expected reduction dim {x.dim() - 1} to have non-zero size.")
+
+
 def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     what = f"{kind}_quantize"
     code = _prep(x, what)
     rows, cols = rows_cols(tuple(x.shape), layerwise)
     if x.numel() == 0:
-        if cols == 0 and not layerwise:
-            raise RuntimeError(f"{what}: cannot reduce over an empty last dimension")  # torch.max raises too
-        if layerwise:
-            raise RuntimeError(f"{what}: cannot reduce an empty tensor")
+        _empty_input(what, x, layerwise)
         return torch.empty_like(x), None, None, None
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(xc)
@@ -265,6 +278,7 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     code = _prep(x, "sym_quantize[autocast]")
     rows, cols = rows_cols(tuple(x.shape), layerwise)
     if x.numel() == 0:
+        _empty_input("sym_quantize[autocast]", x, layerwise)
         return torch.empty(x.shape, dtype=torch.float32 if wide else x.dtype, device=x.device), None, rows, cols, None
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty(xc.shape, dtype=torch.float32 if wide else x.dtype, device=x.device)

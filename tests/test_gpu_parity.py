@@ -321,6 +321,55 @@ def test_error_behaviour_matches_reference(ops):
     assert z.shape == () and float(z) == float(yo[0])
 
 
+@pytest.mark.parametrize("autocast", [False, True])
+def test_degenerate_shapes_behave_like_the_eager_chain(ops, autocast):
+    """Tensors without elements and one-element tensors through SymQuantizer / AsymQuantizer (forward + backward, every backward mode),
+    against the reference's op chain run live on this device (oracle/eager_chain.py restates models/utils_quant.py:37-87, :96-162 op for
+    op): zero ROWS of a non-empty last dimension give an empty result; a reduction over nothing raises what torch.max raises in the
+    reference -- IndexError for an empty reduction dimension, RuntimeError for the layerwise max and for the 4-D branch's ambiguous
+    view(d0, d1, -1);
+    one-element rows quantize to themselves' bins.  Same result, or the same exception TYPE."""
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
+    from oracle import eager_chain as E
+    clip = torch.tensor([-2.0, 2.0])
+
+    def run(q, shape, bits, layerwise):
+        torch.manual_seed(0)
+        x = torch.randn(shape, device="cuda").bfloat16().requires_grad_(True)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                y = q.apply(x, clip, bits, layerwise)
+            y.float().sum().backward()
+        except Exception as e:  # noqa: BLE001
+            return type(e)
+        return y.detach(), x.grad
+
+    prev = llm_qat_amd.get_backward_mode()
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        for shape in [(0, 8), (3, 0), (0,), (2, 0, 8), (2, 3, 0), (0, 0), (0, 3, 4, 8), (2, 3, 0, 8), (2, 0, 4, 8), (2, 3, 4, 0), (0, 0, 4, 8),
+                      (1, 1), (1,), (5, 1), (), (1, 1, 1, 1)]:
+            for layerwise in (False, True):
+                for ref_q, q in ((E.EagerSym, SymQuantizer), (E.EagerAsym, AsymQuantizer)):
+                    if autocast and q is AsymQuantizer:
+                        continue
+                    want = run(ref_q, shape, 8, layerwise)
+                    for mode in ("mask", "bounds", "plain"):
+                        llm_qat_amd.set_backward_mode(mode)
+                        got = run(q, shape, 8, layerwise)
+                        tag = f"{q.__name__} {shape} layerwise={layerwise} autocast={autocast} mode={mode}"
+                        if isinstance(want, type):
+                            assert got is want, f"{tag}: reference raises {want.__name__}, drop-in gave {got if isinstance(got, type) else 'a result'}"
+                        else:
+                            assert not isinstance(got, type), f"{tag}: drop-in raised {got}, the reference returns {tuple(want[0].shape)}"
+                            for a, b in zip(got, want):
+                                assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), tag
+    finally:
+        llm_qat_amd.set_backward_mode(prev)
+        llm_qat_amd.set_semantics("cpu_eager")
+
+
 # ------------------------------------------------------------------------------------------
 # (3) full-size properties (BASELINE.json sizes; the oracle checks a sample of rows)
 # ------------------------------------------------------------------------------------------

@@ -150,3 +150,37 @@ def test_low_bit_weight_branches_equal_the_live_reference(ref, dtype, monkeypatc
             want, _ = O.w12_fwd(w_np, out_f, in_f, w_bits, dtype, scale_in=sc)
         got = to_np(seen["w"])
         assert bits_equal(want.reshape(got.shape), got, dtype), f"trial {trial}: {dtype} [{out_f},{in_f}] w_bits={w_bits} lw={layerwise}: {mismatch_report(want.reshape(got.shape), got, dtype)}"
+
+
+def test_degenerate_shapes_cpu_tensor_path_vs_the_live_reference(ref):
+    """the drop-in's opt-in CPU-tensor path (llm_qat_amd.allow_cpu_tensors) on tensors without elements / with one element: the live
+    reference's result, or the live reference's exception type (tests/test_gpu_parity.py checks the same list on the GPU kernels'
+    host path against the eager chain)"""
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer
+    clip = torch.tensor([-2.0, 2.0])
+
+    def run(q, shape, layerwise):
+        x = torch.full(shape, 0.75).requires_grad_(True)
+        try:
+            y = q.apply(x, clip, 8, layerwise)
+            y.sum().backward()
+        except Exception as e:  # noqa: BLE001
+            return type(e)
+        return y.detach(), x.grad
+
+    llm_qat_amd.allow_cpu_tensors(True)
+    try:
+        for shape in [(0, 8), (3, 0), (0,), (2, 0, 8), (2, 3, 0), (0, 0), (0, 3, 4, 8), (2, 3, 0, 8), (2, 0, 4, 8), (2, 3, 4, 0), (0, 0, 4, 8),
+                      (1, 1), (1,), (5, 1), (), (1, 1, 1, 1), (1, 1, 1, 1, 2)]:
+            for layerwise in (False, True):
+                for rq, q in ((ref.SymQuantizer, SymQuantizer), (ref.AsymQuantizer, AsymQuantizer)):
+                    want, got = run(rq, shape, layerwise), run(q, shape, layerwise)
+                    tag = f"{q.__name__} {shape} layerwise={layerwise}"
+                    if isinstance(want, type):
+                        assert got is want, f"{tag}: reference raises {want.__name__}, drop-in gave {got}"
+                    else:
+                        assert not isinstance(got, type), f"{tag}: drop-in raised {got}"
+                        assert all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(got, want)), tag
+    finally:
+        llm_qat_amd.allow_cpu_tensors(False)

@@ -84,7 +84,8 @@ size_t fq_rowwise_workspace_bytes(int64_t rows, int64_t cols, int dtype);
  * Replaces 9 ATen kernels (abs, max, add, reciprocal, mul, mul, round, add, div) by one pass:
  * x is read once, y written once.  No clamp (the reference has none): 8-bit bf16 bins reach +-128.
  *   x, y      [rows, cols] dtype, contiguous; y may not alias x
- *   bits      2..31 (the callers use 3..16)
+ *   bits      1..31 (the callers use 3..16; with 1 bit the only level is 0 -- qmax = 2^0 - 1 -- and everything quantizes to +-0,
+ *             as in the reference, which the KV hooks' `kv_bits < 32` gate can reach)
  *   row_bounds_out  optional float[rows][2] = {+m, -m}: bounds of the row's values, which
  *             fq_ste_bwd_rows can use to skip re-reading x (pass NULL if unused)
  */

@@ -46,7 +46,7 @@ template <bool ASYM>
 int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, int64_t rows, int64_t cols, int bits, int dtype,
             int sem, void* ws, size_t wsb, void* stream, const MaskArgs* mk = nullptr) {
     if (dtype < 0 || dtype > FQ_DTYPE_F64) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
-    if (bits < (ASYM ? 1 : 2) || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [%d, 31]", bits, ASYM ? 1 : 2);
+    if (bits < 1 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [1, 31]", bits);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape rows=%lld cols=%lld", (long long)rows, (long long)cols);
     if (rows == 0 || cols == 0) return ok();  // empty tensor: nothing to do (the reference returns an empty tensor)
@@ -144,7 +144,7 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
                                void* stream) {
     if (dtype != FQ_DTYPE_BF16 && dtype != FQ_DTYPE_F16)
         return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to bf16 / fp16 tensors (fp32 tensors are unaffected by autocast)");
-    if (bits < 2 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [2, 31]", bits);
+    if (bits < 1 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [1, 31]", bits);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
     if (rows == 0 || cols == 0) return ok();
@@ -179,7 +179,7 @@ FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dty
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "shape not served by the register kernels (see fq_ste_mask_bytes)");
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
-        if (t[i].bits < 2 || t[i].bits > 31) return fail(FQ_ERR_BITS, "num_bits outside [2, 31]");
+        if (t[i].bits < 1 || t[i].bits > 31) return fail(FQ_ERR_BITS, "num_bits outside [1, 31]");
         if (t[i].rows <= 0) return fail(FQ_ERR_SHAPE, "multi-tensor launch needs non-empty tensors");
         if (!t[i].x || !t[i].y) return fail(FQ_ERR_NULL, "multi-tensor launch: x / y of every tensor required");
         if (t[i].mask && !t[i].row_bounds) return fail(FQ_ERR_NULL, "a mask needs its row_bounds too");

@@ -56,7 +56,7 @@ template <bool ASYM>
 int export_entry(const void* x, void* bins, float* scales, int32_t* overflow, int64_t rows, int64_t cols, int bits, int container, int dtype,
                  int sem, int autocast, float lo, float hi, float* bounds, void* mask, size_t mask_bytes, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
-    if (bits < (ASYM ? 1 : 2) || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [%d, 31]", bits, ASYM ? 1 : 2);
+    if (bits < 1 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [1, 31]", bits);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
     if (container < BINS_NONE || container > BINS_INT16) return fail(FQ_ERR_ARG, "unknown bins container %d", container);
     if (autocast && (ASYM || dtype == FQ_DTYPE_F32)) return fail(FQ_ERR_DTYPE, "autocast arithmetic applies to SymQuantizer on bf16 / fp16 tensors only");

@@ -589,7 +589,7 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
     if torch.compiler.is_compiling():
         return (compiled.fake_quant("sym", k, clip_val_k, num_bits, False), compiled.fake_quant("sym", v, clip_val_v, num_bits, False))
     lo, hi = _clip_pair(clip_val_k)
-    if (_PAIR and _BACKWARD_MODE == "mask" and k.is_cuda and _clip_pair(clip_val_v) == (lo, hi) and 2 <= num_bits < 32
+    if (_PAIR and _BACKWARD_MODE == "mask" and k.is_cuda and _clip_pair(clip_val_v) == (lo, hi) and 1 <= num_bits < 32
             and k.dim() <= 3 and v.dim() <= 3):
         grad = torch.is_grad_enabled()
         need_k, need_v = grad and k.requires_grad, grad and v.requires_grad
@@ -655,7 +655,7 @@ def _kv_discard(tid):
 
 def _kv_hook(x, clip_val, num_bits):
     """-> the fake-quantized x if it is served from / by a K+V pair launch, else None (the ordinary single call runs)"""
-    if (not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 2 <= num_bits < 32 and x.dim() <= 3) or x.is_inference()
+    if (not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 1 <= num_bits < 32 and x.dim() <= 3) or x.is_inference()
             or torch.compiler.is_compiling()):
         return None
     tid = threading.get_ident()

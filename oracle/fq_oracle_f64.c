@@ -30,7 +30,7 @@ static inline int32_t idx64_i32(double r) { /* same coding as make_golden.py: Na
 
 /* utils_quant.py:50-72 */
 int fqo64_sym_fwd(const double* x, double* y, int32_t* idx, double* scale, int64_t rows, int64_t cols, int bits) {
-    if (bits < 2 || bits > 31) return -2;
+    if (bits < 1 || bits > 31) return -2;
     const double qmax = (double)((1u << (bits - 1)) - 1u);
     for (int64_t r = 0; r < rows; ++r) {
         const double* xr = x + r * cols;

@@ -43,7 +43,8 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.fq_sym_fwd(None, None, 4, 4, 4, 9, 0, None, None, 0, None) == -1      # dtype
     assert b"dtype" in L.fq_last_error()
-    assert L.fq_sym_fwd(None, None, 4, 4, 1, 1, 0, None, None, 0, None) == -2      # bits
+    assert L.fq_sym_fwd(None, None, 4, 4, 0, 1, 0, None, None, 0, None) == -2      # bits (1..31 are served: 1-bit Sym has the single level 0, as in the reference)
+    assert L.fq_sym_fwd(None, None, 4, 4, 32, 1, 0, None, None, 0, None) == -2
     assert L.fq_asym_fwd(None, None, 4, 4, 32, 1, 0, None, None, 0, None) == -2
     assert L.fq_sym_fwd(None, None, 4, 4, 4, 1, 5, None, None, 0, None) == -7      # semantics
     assert L.fq_sym_fwd(None, None, -1, 4, 4, 1, 0, None, None, 0, None) == -3     # shape

@@ -321,6 +321,55 @@ def test_error_behaviour_matches_reference(ops):
     assert z.shape == () and float(z) == float(yo[0])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_one_bit_sym_is_served_like_the_reference(ops, dtype):
+    """num_bits = 1 for SymQuantizer: qmax = 2**0 - 1 = 0 (models/utils_quant.py:71), so the scale is 0 and every finite element quantizes
+    to a signed zero (NaN / Inf stay NaN) -- useless, but defined, and reachable through the KV hooks' `kv_bits < 32` gate
+    (modeling_llama_quant.py:321).  Kernel == oracle (values + bins), drop-in == live eager chain in every backward mode, with and without
+    autocast, K+V pair launch included; export gives all-zero bins."""
+    import llm_qat_amd
+    from llm_qat_amd.utils_quant import SymQuantizer, quantize_kv
+    from oracle import eager_chain as E
+    clip = torch.tensor([-2.0, 2.0])
+    torch.manual_seed(3)
+    for shape in [(5, 1000), (3, 4096), (2, 7, 264), (4, 11008)]:
+        x = (torch.randn(shape, device="cuda") * 1.7).to(TD[dtype])
+        x.view(-1)[3], x.view(-1)[11] = float("inf"), float("nan")
+        x.view(-1)[5] = -0.0
+        rows, cols = O.rows_cols(tuple(shape), False)
+        yo, io, _ = O.sym_fwd(np_from(x), rows, cols, 1, dtype)
+        y, idx, _ = ops.sym_quantize_debug(x, 1, False)
+        assert (np_from(idx) == io).all() and bits_equal(np_from(y), yo, dtype), f"{dtype} {shape}: {mismatch_report(np_from(y), yo, dtype)}"
+        prev = llm_qat_amd.get_backward_mode()
+        llm_qat_amd.set_semantics("device_eager")
+        try:
+            for autocast in ((False, True) if dtype != "fp32" else (False,)):
+                xr = x.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                    want = E.EagerSym.apply(xr, clip, 1, False)
+                want.float().sum().backward()
+                for mode in ("mask", "bounds", "plain"):
+                    llm_qat_amd.set_backward_mode(mode)
+                    xg = x.clone().requires_grad_(True)
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                        got = SymQuantizer.apply(xg, clip, 1, False)
+                    got.float().sum().backward()
+                    assert got.dtype == want.dtype and bits_equal(np_from(got), np_from(want), "fp32" if got.dtype == torch.float32 else dtype), (dtype, shape, autocast, mode)
+                    assert bits_equal(np_from(xg.grad), np_from(xr.grad), dtype), (dtype, shape, autocast, mode, "grad")
+                if len(shape) <= 3:
+                    llm_qat_amd.set_backward_mode("mask")
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                        kq, vq = quantize_kv(x, x.flip(0).contiguous(), clip, clip, 1)
+                        vw = E.EagerSym.apply(x.flip(0).contiguous(), clip, 1, False)
+                    assert bits_equal(np_from(kq), np_from(want), "fp32" if kq.dtype == torch.float32 else dtype)
+                    assert bits_equal(np_from(vq), np_from(vw), "fp32" if vq.dtype == torch.float32 else dtype)
+        finally:
+            llm_qat_amd.set_backward_mode(prev)
+            llm_qat_amd.set_semantics("cpu_eager")
+        ex = ops.sym_export(x, 1, False, container="int4", autocast=False)
+        assert int(ex.unpacked().abs().max()) == 0
+
+
 @pytest.mark.parametrize("autocast", [False, True])
 def test_degenerate_shapes_behave_like_the_eager_chain(ops, autocast):
     """Tensors without elements and one-element tensors through SymQuantizer / AsymQuantizer (forward + backward, every backward mode),

@@ -71,7 +71,7 @@ def test_oracle_equals_the_live_reference_on_fresh_inputs(ref, dtype):
     for trial in range(n):
         x = draw(rng, dtype, trial)
         kind = "sym" if trial % 3 else "asym"
-        bits = int(rng.choice([2, 3, 4, 6, 8, 12, 16])) if kind == "sym" else int(rng.choice([1, 2, 4, 8, 16]))
+        bits = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 31])) if kind == "sym" else int(rng.choice([1, 2, 4, 8, 16, 24]))
         layerwise = bool(rng.random() < 0.2) and x.dim() <= 3
         lo, hi = [(-2.0, 2.0), (-0.5, 0.75), (-1.0, 1.0)][int(rng.integers(0, 3))]
         clip = torch.tensor([lo, hi])
@@ -101,7 +101,7 @@ def test_oracle_equals_the_live_reference_under_the_autocast_policy(ref, dtype, 
         x = draw(rng, dtype, trial)
         if x.dim() > 3 and trial % 2:
             x = x.reshape(-1, x.shape[-1])
-        bits = int(rng.choice([2, 3, 4, 8, 12, 16]))
+        bits = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 31]))
         lo, hi = [(-2.0, 2.0), (-0.5, 0.75)][trial % 2]
         xr = x.clone().requires_grad_(True)
         with cuda_autocast_policy(TD[dtype], device_scalars), np.errstate(all="ignore"):

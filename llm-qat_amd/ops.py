@@ -48,6 +48,19 @@ def rows_cols(shape, layerwise):
     raise ValueError(f"fake-quant expects at most 4 dimensions, got {nd}")  # utils_quant.py:70
 
 
+def bits_arg(num_bits):
+    """`num_bits` as the Python int the kernels take.  The reference computes `2 ** (num_bits - 1) - 1` in Python and then
+    `int / Tensor` (= reciprocal * int, models/utils_quant.py:71), so an integral float means the same thing; a NON-integral float would
+    mean a fractional number of levels and a TENSOR would turn that line into a true Tensor / Tensor division (different roundings) --
+    neither is what any caller of the reference passes, and neither is served: refused loudly rather than silently truncated."""
+    if isinstance(num_bits, torch.Tensor):
+        raise TypeError("num_bits must be a Python int (a tensor changes the reference's arithmetic to a true division: not served)")
+    b = int(num_bits)
+    if b != num_bits:
+        raise ValueError(f"num_bits must be integral, got {num_bits!r}")
+    return b
+
+
 def _prep(x, what):
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{what}: expected a torch.Tensor, got {type(x).__name__}")

@@ -132,6 +132,8 @@ class _FakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False, inplace_grad=False):
         ctx.fq_inplace = inplace_grad  # a QuantizeLinear's own weight: its gradient may be masked where it stands (point 6 below)
+        if type(num_bits) is not int:
+            num_bits = ops.bits_arg(num_bits)   # 8.0 -> 8; 7.5 or a tensor: refused (ops.bits_arg says why)
         if torch.compiler.is_compiling():  # Dynamo traces forward/backward of the Function: same kernels as custom ops (compiled.py)
             ctx.save_for_backward(input, clip_val)
             ctx.fq_mode = "compiled"
@@ -220,7 +222,7 @@ class SymQuantizer(_FakeQuantFunction):
     @classmethod
     def apply(cls, input, clip_val, num_bits, layerwise):
         # the unchanged KV-cache hooks (two consecutive apply calls on k_proj's and v_proj's outputs): one launch, see point 7
-        if _PAIR_KV and cls is SymQuantizer and not layerwise and not torch._C._are_functorch_transforms_active():
+        if _PAIR_KV and cls is SymQuantizer and not layerwise and type(num_bits) is int and not torch._C._are_functorch_transforms_active():
             out = _kv_hook(input, clip_val, num_bits)
             if out is not None:
                 return out
@@ -586,6 +588,8 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
     length, same launch shape).  Results and gradients are bit-identical to the two calls; under autocast both come
     back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served."""
     k, v = key_states, value_states
+    if type(num_bits) is not int:
+        num_bits = ops.bits_arg(num_bits)
     if torch.compiler.is_compiling():
         return (compiled.fake_quant("sym", k, clip_val_k, num_bits, False), compiled.fake_quant("sym", v, clip_val_v, num_bits, False))
     lo, hi = _clip_pair(clip_val_k)

@@ -126,6 +126,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
 
 
+def test_num_bits_must_mean_what_it_means_in_the_reference():
+    """The reference turns num_bits into `2 ** (num_bits - 1) - 1` in Python and divides that int by a tensor (reciprocal * int, :71): an
+    integral float is the same thing; a fractional float (fractional levels) or a tensor (true Tensor / Tensor division: other roundings)
+    would silently compute something else if truncated -- refused loudly, before any device work"""
+    import torch
+    from llm_qat_amd import ops
+    from llm_qat_amd.utils_quant import AsymQuantizer, SymQuantizer, quantize_kv
+    assert ops.bits_arg(8) == 8 and ops.bits_arg(8.0) == 8 and ops.bits_arg(True) == 1
+    clip, x = torch.tensor([-2.0, 2.0]), torch.zeros(2, 8)
+    for q in (SymQuantizer, AsymQuantizer):
+        with pytest.raises(ValueError, match="integral"):
+            q.apply(x, clip, 7.5, False)
+        with pytest.raises(TypeError, match="Python int"):
+            q.apply(x, clip, torch.tensor(8), False)
+    with pytest.raises(TypeError, match="Python int"):
+        quantize_kv(x, x, clip, clip, torch.tensor(4))
+
+
 def test_product_never_imports_the_oracle():
     """the oracle is test infrastructure: nothing under llm-qat_amd/ may reference it"""
     pkg = os.path.join(ROOT, "llm-qat_amd")

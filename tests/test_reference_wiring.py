@@ -61,3 +61,53 @@ def test_reference_model_builds_on_the_dropin_with_identical_parameters():
         model(input_ids=torch.randint(2, 128, (1, 8)), use_cache=False)
     for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
         del sys.modules[name]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("w_bits,a_bits,kv_bits", [(4, 8, 4), (8, 8, 8), (2, 8, 16), (1, 8, 32)])
+def test_real_reference_model_on_the_dropin_cpu_path_equals_the_real_reference(w_bits, a_bits, kv_bits, dtype):
+    """The REAL model code (models/modeling_llama_quant.py: 7 QuantizeLinear per layer, the KV hooks, gradient flow through all of it) run
+    twice on CPU tensors, live: on the reference's own models/utils_quant.py, and on the drop-in with its opt-in CPU-tensor path
+    (llm_qat_amd.allow_cpu_tensors: the product's own torch ops, with the shared activation fake-quant of the host logic active).
+    Loss, logits and every parameter gradient bit-identical -- W4-A8-KV4, W8-A8-KV8, and the 1-/2-bit weight branches."""
+    import llm_qat_amd
+
+    def step(cfg_mod, mdl_mod, state=None):
+        cfg = cfg_mod.LlamaConfig(vocab_size=128, hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4,
+                                  max_position_embeddings=32, w_bits=w_bits, a_bits=a_bits, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+        cfg.kv_bits = kv_bits
+        cfg.use_cache = False
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = mdl_mod.LlamaForCausalLM(cfg)
+        if state is not None:
+            model.load_state_dict(state)
+        model = model.to(dtype)
+        ids = torch.randint(2, 128, (2, 12), generator=torch.Generator().manual_seed(1))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = model(input_ids=ids, labels=ids, use_cache=False)
+        out.loss.backward()
+        return model, out.loss.detach(), out.logits.detach(), {n: p.grad for n, p in model.named_parameters()}
+
+    ref_model, ref_loss, ref_logits, ref_grads = step(*_fresh_import(swap=False))
+    state = {k: v.float() for k, v in ref_model.state_dict().items()}
+    llm_qat_amd.allow_cpu_tensors(True)
+    llm_qat_amd.stats(reset=True)
+    try:
+        cfg_mod, mdl_mod = _fresh_import(swap=True)
+        _, loss, logits, grads = step(cfg_mod, mdl_mod, state)    # the reference model's own weights (exact in fp32 for either dtype)
+        assert torch.equal(loss, ref_loss), (float(loss), float(ref_loss))
+        assert torch.equal(logits, ref_logits)
+        assert set(grads) == set(ref_grads)
+        for n in ref_grads:
+            assert (grads[n] is None) == (ref_grads[n] is None) and (grads[n] is None or torch.equal(grads[n], ref_grads[n])), n
+        st = llm_qat_amd.stats()
+        if 2 < a_bits < 32:
+            assert st.get("act_share_hit", 0) >= 2 * 3, st     # q/k/v and gate/up found their input already fake-quantized, per layer
+    finally:
+        llm_qat_amd.allow_cpu_tensors(False)
+        llm_qat_amd.reset_learned_state()
+        for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+            del sys.modules[name]

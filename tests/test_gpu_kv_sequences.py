@@ -26,6 +26,8 @@ def build(Q, n=4, d=64):
             m.weight.copy_((torch.randn(d, d, generator=torch.Generator().manual_seed(20 + k)) * 0.4).cuda().bfloat16())
     x = (torch.randn(2, 9, d, generator=torch.Generator().manual_seed(3)) * 1.5).cuda().bfloat16().requires_grad_(True)
     return mods, x
+
+
 def C(lo=-2.0, hi=2.0):
     return torch.tensor([lo, hi])
 

@@ -426,7 +426,12 @@ _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every
 #    fake-quantize the SAME activation tensor with the same bits.  `_shared_activation` remembers the
 #    last (input -> output) pair per thread and hands the same output (and autograd node) to the
 #    sibling projections.  Gradients are unchanged bit for bit: the STE mask is applied once to the
-#    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum.
+#    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum -- as long as
+#    the sharing siblings are the LAST consumers of that input to be created (q/k/v, gate/up: every call
+#    site of the reference model).  If yet another consumer of the same tensor is created after them
+#    (a differently configured quantizer, any other op), the input's gradient is the same sum accumulated
+#    in a different association order: (others + (g_a + g_b)) instead of ((others + g_a) + g_b) -- last-bit
+#    differences in 16-bit dtypes, none in exact arithmetic (tests/test_gpu_share_sequences.py).
 #    A hit requires the very same tensor object at the same version and that no fake-quant backward has run
 #    since (so an output whose graph was already consumed is never handed out again); the remembered outputs are
 #    released when the next backward starts, or replaced by the next module that quantizes an activation the same way.
@@ -481,15 +486,17 @@ def _backward_started():
             _kv_discard(tid)
 
 
-_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch)}
+_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch, input.requires_grad)}
 
 
 def _act_lookup(key, x):
     cache = _act_caches.get(threading.get_ident())
     ent = cache.get(key) if cache else None
     if ent is not None:
-        rin, ver_in, y, ver_out, epoch = ent
-        if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0]:
+        rin, ver_in, y, ver_out, epoch, needs_grad = ent
+        # (requires_grad can be switched on a leaf between two sibling calls without touching its version counter: an output built
+        # without a graph must not be handed to a call that needs one, nor the reverse)
+        if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch[0] and needs_grad == x.requires_grad:
             return y
     return None
 
@@ -503,7 +510,7 @@ def _act_store(key, x, y):
     cache = _act_caches.get(tid)
     if cache is None:
         cache = _act_caches[tid] = {}
-    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch[0])
+    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch[0], x.requires_grad)
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):

@@ -143,3 +143,58 @@ def test_weight_frozen_after_a_step_and_module_pickle():
     buf.seek(0)
     m2 = torch.load(buf, weights_only=False)
     assert torch.equal(m(x.detach()), m2(x.detach()))
+
+
+def test_low_bit_weight_branches_across_dtype_and_autocast_mixes():
+    """QuantizeLinear with w_bits 1 / 2 (utils_quant.py:202-242) for every weight dtype x input dtype x autocast dtype, row-wise and
+    layerwise, with and without activation fake-quant, shapes the one-launch kernel serves and shapes it does not: output, input gradient
+    and weight gradient bit-identical to the branch's op chain run live by ATen (432 combinations)"""
+    import torch.nn.functional as F
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    from oracle import eager_chain as E
+    from test_gpu_features import eager_low_bit
+    clip = torch.tensor([-2.0, 2.0])
+    llm_qat_amd.set_semantics("device_eager")
+    bad = []
+    try:
+        for acdt in (None, torch.bfloat16, torch.float16):
+            for wdt in (torch.float32, torch.bfloat16, torch.float16):
+                for xdt in (torch.float32, torch.bfloat16):
+                    for wb in (1, 2):
+                        for lw in (False, True):
+                            for (o, i) in ((24, 300), (64, 4096), (3, 8)):
+                                for ab in (8, 32):
+                                    torch.manual_seed(0)
+                                    lin = UQ.QuantizeLinear(i, o, w_bits=wb, a_bits=ab, weight_layerwise=lw).cuda().to(wdt)
+                                    with torch.no_grad():
+                                        lin.weight.copy_(torch.randn(o, i, device="cuda") * 0.05)
+                                    x = torch.randn(5, i, device="cuda").to(xdt).requires_grad_(True)
+                                    wref, xr = lin.weight.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True)
+
+                                    def ref():
+                                        with torch.autocast("cuda", dtype=acdt or torch.bfloat16, enabled=acdt is not None):
+                                            y = F.linear(E.EagerSym.apply(xr, clip, ab, False) if ab < 32 else xr, eager_low_bit(wref, wb, lw))
+                                        y.float().sum().backward()
+                                        return [y.detach(), xr.grad, wref.grad]
+
+                                    def got():
+                                        with torch.autocast("cuda", dtype=acdt or torch.bfloat16, enabled=acdt is not None):
+                                            y = lin(x)
+                                        y.float().sum().backward()
+                                        return [y.detach(), x.grad, lin.weight.grad]
+
+                                    res = []
+                                    for f in (ref, got):
+                                        try:
+                                            res.append(f())
+                                        except Exception as e:  # noqa: BLE001
+                                            res.append(type(e))
+                                    a, b = res
+                                    ok = (a is b) if isinstance(a, type) or isinstance(b, type) else same(a, b)
+                                    if not ok:
+                                        bad.append((acdt, wdt, xdt, wb, lw, (o, i), ab))
+        assert not bad, bad[:10]
+    finally:
+        llm_qat_amd.set_semantics("cpu_eager")
+        llm_qat_amd.reset_learned_state()

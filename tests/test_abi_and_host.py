@@ -288,3 +288,40 @@ def test_conservative_switch_turns_every_stateful_host_optimisation_off_and_back
     finally:
         UQ._PAIR, UQ._SHARE_ACT, UQ._PAIR_KV, UQ._INPLACE_WGRAD = before["_PAIR"], before["_SHARE_ACT"], before["_PAIR_KV"], before["_INPLACE_WGRAD"]
         llm_qat_amd.enable_weight_quant_cache(before["_WEIGHT_CACHE"])
+
+
+def test_abi_rejects_null_pointers_and_hostile_sizes_before_any_launch():
+    """Fuzz of every exported entry point with NULL pointers and hostile integers / floats (no GPU needed: validation comes first): each
+    call RETURNS -- a validation code, or 0 for an empty shape -- and none gets as far as a launch (FQ_ERR_LAUNCH), i.e. a NULL can never
+    reach a kernel."""
+    import ctypes
+    import random
+    from llm_qat_amd import _lib
+    L = _lib.lib()
+    rng = random.Random(0)
+    ints = [-(2 ** 63), -(2 ** 31) - 1, -2, -1, 0, 1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 255, 256, 4096, 11008, 2 ** 31 - 1, 2 ** 31, 2 ** 32, 2 ** 40, 2 ** 62]
+    floats = [0.0, -0.0, 1.0, -2.0, 2.0, float("inf"), float("-inf"), float("nan"), 1e-45, 3e38]
+    launching = [n for n in _lib.EXPORTS if n not in ("fq_version", "fq_build_info", "fq_last_error", "fq_rowwise_workspace_bytes", "fq_ste_mask_bytes",
+                                                      "fq_export_bins_bytes")]
+    calls = 0
+    for name in launching:
+        f = getattr(L, name)
+        for _ in range(400):
+            args = []
+            for t in f.argtypes:
+                if t is ctypes.c_void_p:
+                    args.append(None)
+                elif t is ctypes.c_float:
+                    args.append(rng.choice(floats))
+                elif t is ctypes.c_int64:
+                    args.append(rng.choice(ints))
+                elif t is ctypes.c_size_t:
+                    args.append(rng.choice([v for v in ints if v >= 0]))
+                elif t is ctypes.c_int:
+                    args.append(max(-(2 ** 31), min(2 ** 31 - 1, rng.choice(ints))))
+                else:   # POINTER(struct) of the multi-tensor entry points: NULL, or a table of zeroed slots
+                    args.append(None if rng.random() < 0.5 else (t._type_ * _lib.MAX_TENSORS)())
+            rc = f(*args)
+            calls += 1
+            assert rc in (0, -1, -2, -3, -4, -5, -7, -8), f"{name}{tuple(args)} -> {rc}: {L.fq_last_error().decode(errors='replace')}"
+    assert calls == 400 * len(launching)

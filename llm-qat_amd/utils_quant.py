@@ -187,6 +187,8 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "cpu":
             input, clip_val = ctx.saved_tensors
             return cpu_tensors.backward(grad_output, input, clip_val), None, None, None
+        if ctx.fq_mode == "none":   # the input needs no gradient; the engine is here for a clip_val that requires grad -- which gets None (:87)
+            return None, None, None, None
         inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
         _backward_started(ctx.fq_tid)
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass

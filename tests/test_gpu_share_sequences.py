@@ -165,3 +165,21 @@ def test_a_later_consumer_changes_only_the_association_order_of_the_input_gradie
         llm_qat_amd.share_activation_quant(True)
         llm_qat_amd.set_semantics("cpu_eager")
         llm_qat_amd.reset_learned_state()
+
+
+def test_clip_val_requiring_grad_while_the_input_does_not():
+    """the reference's backward returns None for clip_val (:87) whatever needs a gradient; with an input that needs none the drop-in records
+    nothing in the forward and must still answer the engine"""
+    import llm_qat_amd.utils_quant as UQ
+    from oracle import eager_chain as E
+    x = torch.randn(4, 64, device="cuda").bfloat16()
+    for q in (E.EagerSym, UQ.SymQuantizer, UQ.AsymQuantizer):
+        clip = torch.tensor([-2.0, 2.0], requires_grad=True)
+        y = q.apply(x, clip, 8, False)
+        if y.requires_grad:
+            y.float().sum().backward()
+        assert clip.grad is None
+    xg = x.clone().requires_grad_(True)
+    clip = torch.tensor([-2.0, 2.0], requires_grad=True)
+    UQ.SymQuantizer.apply(xg, clip, 8, False).float().sum().backward()
+    assert clip.grad is None and xg.grad is not None

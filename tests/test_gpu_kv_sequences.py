@@ -149,6 +149,8 @@ def test_kv_hook_sequences_match_the_eager_chain(name, autocast):
     import llm_qat_amd.utils_quant as UQ
     fn, (launched, hit, discarded) = SCENARIOS[name]
     llm_qat_amd.set_semantics("device_eager")
+    prev_mode = llm_qat_amd.get_backward_mode()
+    llm_qat_amd.set_backward_mode("mask")      # the speculation (and the counters asserted below) belong to the default data flow
     try:
         llm_qat_amd.reset_learned_state()
         want = fn(TL.EagerQuant(), autocast)
@@ -162,5 +164,6 @@ def test_kv_hook_sequences_match_the_eager_chain(name, autocast):
             elif discarded:
                 assert not st.get("kv_pair_launch"), st     # a signature that was wrong once stops speculating
     finally:
+        llm_qat_amd.set_backward_mode(prev_mode)
         llm_qat_amd.set_semantics("cpu_eager")
         llm_qat_amd.reset_learned_state()

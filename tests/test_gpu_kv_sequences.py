@@ -167,3 +167,69 @@ def test_kv_hook_sequences_match_the_eager_chain(name, autocast):
         llm_qat_amd.set_backward_mode(prev_mode)
         llm_qat_amd.set_semantics("cpu_eager")
         llm_qat_amd.reset_learned_state()
+
+
+def _g(*shape, dt=torch.bfloat16, grad=True, seed=0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * 1.5).cuda().to(dt).requires_grad_(grad)
+
+
+def _noncontig():
+    a, b = _g(9, 2, 64), _g(9, 2, 64, seed=1)
+    return a.transpose(0, 1), b.transpose(0, 1)
+
+
+QKV_CASES = {
+    "plain [2,9,64]": (lambda: (_g(2, 9, 64), _g(2, 9, 64, seed=1)), {}),
+    "different shapes": (lambda: (_g(2, 9, 64), _g(2, 5, 64, seed=1)), {}),
+    "different widths": (lambda: (_g(2, 9, 64), _g(2, 9, 32, seed=1)), {}),
+    "different dtypes": (lambda: (_g(2, 9, 64), _g(2, 9, 64, dt=torch.float16, seed=1)), {}),
+    "fp32 pair": (lambda: (_g(2, 9, 64, dt=torch.float32), _g(2, 9, 64, dt=torch.float32, seed=1)), {}),
+    "K grad, V no grad": (lambda: (_g(2, 9, 64), _g(2, 9, 64, grad=False, seed=1)), {}),
+    "neither needs grad": (lambda: (_g(2, 9, 64, grad=False), _g(2, 9, 64, grad=False, seed=1)), {}),
+    "different clips": (lambda: (_g(2, 9, 64), _g(2, 9, 64, seed=1)), {"cv": (-1.0, 1.0)}),
+    "4-D inputs": (lambda: (_g(2, 3, 4, 16), _g(2, 3, 4, 16, seed=1)), {}),
+    "1-D inputs": (lambda: (_g(64), _g(64, seed=1)), {}),
+    "no rows": (lambda: (_g(0, 64), _g(0, 64, seed=1)), {}),
+    "1 bit": (lambda: (_g(2, 9, 64), _g(2, 9, 64, seed=1)), {"bits": 1}),
+    "16 bits": (lambda: (_g(2, 9, 64), _g(2, 9, 64, seed=1)), {"bits": 16}),
+    "the same tensor as K and V": (lambda: (lambda t: (t, t))(_g(2, 9, 64)), {}),
+    "non-contiguous views": (_noncontig, {}),
+    "odd width 100": (lambda: (_g(3, 100), _g(3, 100, seed=1)), {}),
+}
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("name", list(QKV_CASES))
+def test_quantize_kv_equals_the_two_reference_calls(name, autocast):
+    """llm_qat_amd.quantize_kv(K, V, clip_k, clip_v, bits) -- the two-line call-site change of INTEGRATION.md -- against the two
+    SymQuantizer.apply calls it stands for (modeling_llama_quant.py:320-327) on the live eager chain, whatever it is handed: it pairs what
+    it can and falls back to two calls for the rest; values, gradients, dtypes (fp32 under autocast) bit-identical, or the same exception."""
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    from oracle import eager_chain as E
+    mk, kw = QKV_CASES[name]
+    ck, cv, bits = kw.get("ck", (-2.0, 2.0)), kw.get("cv", (-2.0, 2.0)), kw.get("bits", 4)
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        res = []
+        for which in ("ref", "got"):
+            k, v = mk()
+            try:
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                    if which == "ref":
+                        kq, vq = E.EagerSym.apply(k, torch.tensor(ck), bits, False), E.EagerSym.apply(v, torch.tensor(cv), bits, False)
+                    else:
+                        kq, vq = UQ.quantize_kv(k, v, torch.tensor(ck), torch.tensor(cv), bits)
+                if kq.requires_grad or vq.requires_grad:
+                    (kq.float().sum() + 2 * vq.float().sum()).backward()
+                res.append([kq.detach(), vq.detach(), k.grad if k.is_leaf else None, v.grad if v.is_leaf else None])
+            except Exception as e:  # noqa: BLE001
+                res.append(type(e))
+        want, got = res
+        if isinstance(want, type) or isinstance(got, type):
+            assert want is got, (want, got)
+        else:
+            assert same(want, got), name
+    finally:
+        llm_qat_amd.set_semantics("cpu_eager")
+        llm_qat_amd.reset_learned_state()

@@ -225,6 +225,17 @@ def build_fwd(kind):
         else:
             x = act_like(gen, shape, dt)
         emit(f"{kind}_{dname}_b{bits}_model_{'x'.join(map(str, shape))}", x, bits, False, dname)
+
+    # the ends of the bit-width domain (round 4; appended with their own generator so that every earlier array regenerates byte-identical):
+    # 1-bit Sym has qmax = 2**0 - 1 = 0 -- reachable through the KV hooks' `kv_bits < 32` gate --, 2 and 31 bits are the other Sym ends;
+    # Asym: 1 and 24 bits
+    gen2 = torch.Generator().manual_seed(9876 if kind == "sym" else 6789)
+    for dname, dt in DT.items():
+        for bits in ((1, 2, 31) if kind == "sym" else (1, 24)):
+            for shape in [(3, 7), (2, 255), (2, 3, 64)]:
+                emit(f"{kind}_{dname}_b{bits}_edge_{'x'.join(map(str, shape))}", rand_rows(gen2, shape, dt), bits, False, dname)
+            xa, names = adversarial(dt)
+            emit(f"{kind}_{dname}_b{bits}_edge_adversarial", xa, bits, False, dname, extra=dict(row_names=names))
     return arrays, manifest
 
 

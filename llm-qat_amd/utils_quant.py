@@ -105,6 +105,12 @@ def _graph_aware(backward):
     return wrapper
 
 
+# _no_gradient: every Function below sets ctx.set_materialize_grads(False) and answers a gradient that never arrived with None.  The K/V
+# speculation (point 7) can make a tensor an input of a node whose result nobody uses; with materialised zeros the parameters behind that
+# tensor would end a step with a ZERO .grad where the reference leaves None -- and an optimizer treats the two differently (weight decay,
+# moments).  With None all the way, a dead branch stays dead (tests/test_gpu_random_programs.py found this).
+
+
 class _FakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def _fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow):
@@ -140,6 +146,7 @@ class _FakeQuantFunction(torch.autograd.Function):
             return compiled.fake_quant(kind, input, clip_val, num_bits, layerwise, narrow)
         ctx.grad_dtype = None
         ctx.fq_tid = threading.get_ident()   # whose forward pass this node belongs to (_backward_started)
+        ctx.set_materialize_grads(False)     # a gradient that never arrives stays None (see _no_gradient)
         if input.device.type == "cpu":   # opt-in, plain torch ops (cpu_tensors.py): never a fallback for a CUDA tensor
             if not cpu_tensors.ENABLED:
                 cpu_tensors.refuse(input, f"{kind}_quantize")
@@ -184,11 +191,11 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "compiled":
             input, clip_val = ctx.saved_tensors
             return compiled.fake_quant_bwd(grad_output, input, clip_val), None, None, None
+        if ctx.fq_mode == "none" or grad_output is None:   # nothing to mask: the input needs no gradient (the engine is here for a clip_val
+            return None, None, None, None                  # that requires grad, which gets None, :87), or no gradient arrived (_no_gradient)
         if ctx.fq_mode == "cpu":
             input, clip_val = ctx.saved_tensors
             return cpu_tensors.backward(grad_output, input, clip_val), None, None, None
-        if ctx.fq_mode == "none":   # the input needs no gradient; the engine is here for a clip_val that requires grad -- which gets None (:87)
-            return None, None, None, None
         inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
         _backward_started(ctx.fq_tid)
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
@@ -263,6 +270,7 @@ class _LowBitWeightCpu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, w_bits, layerwise):
+        ctx.set_materialize_grads(False)
         return cpu_tensors.low_bit_weight(w, w_bits, layerwise)
 
     @staticmethod
@@ -276,6 +284,7 @@ class _LowBitWeight(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, scale, w_bits):
+        ctx.set_materialize_grads(False)
         return ops.low_bit_weight(w, scale, w_bits)
 
     @staticmethod
@@ -288,6 +297,7 @@ class _LowBitWeightFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, w_bits):
+        ctx.set_materialize_grads(False)
         res = ops.low_bit_weight_fused(w, w_bits)
         if res is None:
             raise _NotServed()
@@ -745,12 +755,15 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
         y, bounds, mask, rows_cols = cached
         ctx.rows_cols = rows_cols
         ctx.clip = _clip_pair(clip_val)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(weight if mask is None else None, bounds, mask)
         return y.view_as(y)
 
     @staticmethod
     @_graph_aware
     def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None, None
         inplace = _INPLACE_WGRAD and _inplace_ok(grad_output)
         lo, hi = ctx.clip
         weight, row_bounds, ste_mask = ctx.saved_tensors
@@ -769,12 +782,15 @@ class _PrecomputedAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, side, rows, cols, clip):
         ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_tid = (rows, cols), clip, x.dtype, threading.get_ident()
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(side)
         return y.view_as(y)
 
     @staticmethod
     @_graph_aware
     def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None, None, None, None, None
         _backward_started(ctx.fq_tid)
         (side,) = ctx.saved_tensors
         lo, hi = ctx.clip

@@ -1,0 +1,139 @@
+"""GPU tier: RANDOM PROGRAMS over the drop-in -- a generator builds a small graph out of QuantizeLinear layers (random w_bits incl. 1 / 2 /
+32, a_bits incl. off, Sym / Asym, layerwise flags), KV-hook style SymQuantizer.apply calls, elementwise glue, no_grad regions, tensors that
+do or do not require grad, then backpropagates a random loss -- and runs it twice: on the live eager chain (tiny_llama.EagerQuant over
+oracle/eager_chain.py, plus the 1-/2-bit branch's op chain) and on the drop-in at default settings.
+
+What must hold for every program: the same outputs bit for bit; the same set of tensors receiving a gradient; with the shared activation
+fake-quant OFF every gradient bit for bit; with it ON every gradient equal up to the association order of bf16 sums (a documented limit of
+sharing when the shared input has further consumers: utils_quant.py point 1) -- close in a norm, never a different support.
+"""
+import os
+import random
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tiny_llama as TL  # noqa: E402
+
+D = 64
+PROGRAMS = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "60"))
+
+
+class EagerLowBitLinear(nn.Linear):
+    """the reference's QuantizeLinear for w_bits 1 / 2 (utils_quant.py:202-242), op for op, activations through the eager chain"""
+
+    def __init__(self, i, o, w_bits, a_bits, symmetric, act_layerwise, weight_layerwise, E):
+        super().__init__(i, o, bias=False)
+        self.w_bits, self.a_bits, self.alw, self.wlw = w_bits, a_bits, act_layerwise, weight_layerwise
+        self.act_q = (E.EagerSym if symmetric else E.EagerAsym) if 2 < a_bits < 32 else None
+
+    def forward(self, x):
+        from test_gpu_features import eager_low_bit
+        w = eager_low_bit(self.weight, self.w_bits, self.wlw)
+        if self.act_q is not None:
+            x = self.act_q.apply(x, torch.tensor([-2.0, 2.0]), self.a_bits, self.alw)
+        return F.linear(x, w)
+
+
+def make_module(Q, eager, cfg):
+    from oracle import eager_chain as E
+    w_bits, a_bits, sym, alw, wlw, seed = cfg
+    if eager and w_bits < 3:
+        m = EagerLowBitLinear(D, D, w_bits, a_bits, sym, alw, wlw, E)
+    elif eager:
+        m = Q.QuantizeLinear(D, D, symmetric=sym, w_bits=w_bits, a_bits=a_bits, act_layerwise=alw, weight_layerwise=wlw)
+    else:
+        m = Q.QuantizeLinear(D, D, symmetric=sym, w_bits=w_bits, a_bits=a_bits, act_layerwise=alw, weight_layerwise=wlw)
+    m = m.cuda().bfloat16()
+    with torch.no_grad():
+        m.weight.copy_((torch.randn(D, D, generator=torch.Generator().manual_seed(seed)) * 0.3).cuda().bfloat16())
+        m.weight[1, 2] = 2.5
+    return m
+
+
+def gen_program(rng):
+    mods = [(rng.choice([1, 2, 4, 4, 8, 32]), rng.choice([4, 8, 8, 8, 32]), rng.random() < 0.85, rng.random() < 0.1, rng.random() < 0.1, rng.randrange(10 ** 6))
+            for _ in range(rng.randint(2, 6))]
+    inputs = [(rng.random() < 0.8, rng.randrange(10 ** 6)) for _ in range(rng.randint(1, 2))]
+    steps, n_t = [], len(inputs)
+    for _ in range(rng.randint(3, 12)):
+        kind = rng.choices(["linear", "hook", "scale", "add", "nograd_linear"], [6, 3, 1, 1, 1])[0]
+        if kind in ("linear", "nograd_linear"):
+            steps.append((kind, rng.randrange(len(mods)), rng.randrange(n_t)))
+        elif kind == "hook":
+            steps.append((kind, rng.choice([1, 2, 4, 8]), rng.randrange(n_t), rng.choice([(-2.0, 2.0), (-2.0, 2.0), (-1.0, 1.5)])))
+        elif kind == "scale":
+            steps.append((kind, rng.choice([0.5, 1.5, -1.0]), rng.randrange(n_t)))
+        else:
+            steps.append((kind, rng.randrange(n_t), rng.randrange(n_t)))
+        n_t += 1
+    loss = [(i, rng.choice([1.0, 2.0, -0.5])) for i in range(len(inputs), n_t) if rng.random() < 0.6] or [(n_t - 1, 1.0)]
+    return mods, inputs, steps, loss, rng.random() < 0.5
+
+
+def run_program(Q, eager, prog):
+    mods_cfg, inputs, steps, loss, autocast = prog
+    mods = [make_module(Q, eager, c) for c in mods_cfg]
+    ts = [(torch.randn(2, 7, D, generator=torch.Generator().manual_seed(seed)) * 1.5).cuda().bfloat16().requires_grad_(g) for g, seed in inputs]
+    n_in = len(ts)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        for st in steps:
+            if st[0] == "linear":
+                ts.append(mods[st[1]](ts[st[2]].to(torch.bfloat16)))
+            elif st[0] == "nograd_linear":
+                with torch.no_grad():
+                    ts.append(mods[st[1]](ts[st[2]].to(torch.bfloat16)))
+            elif st[0] == "hook":
+                ts.append(Q.SymQuantizer.apply(ts[st[2]], torch.tensor(st[3]), st[1], False))
+            elif st[0] == "scale":
+                ts.append(ts[st[2]] * st[1])
+            else:
+                ts.append(ts[st[1]].float() + ts[st[2]].float())
+    total = sum(ts[i].float().sum() * w for i, w in loss)
+    if total.requires_grad:
+        total.backward()
+    outs = [t.detach() for t in ts[n_in:]]
+    grads = [t.grad for t in ts[:n_in]] + [m.weight.grad for m in mods]
+    return outs, grads
+
+
+def check_program(seed, share):
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    prog = gen_program(random.Random(seed))
+    llm_qat_amd.reset_learned_state()
+    want_o, want_g = run_program(TL.EagerQuant(), True, prog)
+    llm_qat_amd.share_activation_quant(share)
+    llm_qat_amd.reset_learned_state()
+    got_o, got_g = run_program(UQ, False, prog)
+    tag = f"program seed={seed} share={share}: {prog}"
+    assert len(want_o) == len(got_o)
+    for i, (a, b) in enumerate(zip(want_o, got_o)):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.nan_to_num(), b.nan_to_num()), f"output {i} of {tag}"
+    for i, (a, b) in enumerate(zip(want_g, got_g)):
+        assert (a is None) == (b is None), f"gradient {i} present in one run only, {tag}"
+        if a is None:
+            continue
+        if share:   # association order of bf16 sums may differ where a shared input has further consumers: same support, close in a norm
+            assert torch.equal(a == 0, b == 0) or float((a.float() - b.float()).abs().max()) <= 2 ** -5 * float(a.float().abs().max() + 1e-6), f"gradient {i} of {tag}"
+            assert float((a.float() - b.float()).norm()) <= 2 ** -5 * float(a.float().norm() + 1e-6), f"gradient {i} of {tag}"
+        else:
+            assert torch.equal(a, b), f"gradient {i} of {tag}"
+
+
+@pytest.mark.parametrize("share", [False, True])
+def test_random_programs_match_the_eager_chain(share):
+    import llm_qat_amd
+    llm_qat_amd.set_semantics("device_eager")
+    try:
+        for seed in range(PROGRAMS):
+            check_program(seed, share)
+    finally:
+        llm_qat_amd.share_activation_quant(True)
+        llm_qat_amd.set_semantics("cpu_eager")
+        llm_qat_amd.reset_learned_state()

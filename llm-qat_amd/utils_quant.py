@@ -500,7 +500,20 @@ def _backward_started(tid):
         _kv_discard(tid)
 
 
-_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch, input.requires_grad)}
+_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch, input.requires_grad, region)}
+_top_hooks = getattr(torch._C._autograd, "_top_saved_tensors_default_hooks", None)
+
+
+def _region():
+    """Which saved-tensor-hooks context this call runs in (its pack hook: a fresh object per context; None outside any).  Non-reentrant
+    activation checkpointing is such a context -- one for the first pass, another for the recompute -- and requires both passes to save
+    the same tensors: something remembered OUTSIDE a checkpointed region must not be used INSIDE it (the recompute, which starts from an
+    empty memory, could not repeat that), so what is remembered is only handed out within the region it was made in.  A checkpoint
+    around a whole decoder layer -- the reference's, modeling_llama_quant.py:732-747 -- contains all siblings and loses nothing."""
+    if _top_hooks is None:
+        return None
+    h = _top_hooks(True)
+    return None if h is None else h[0]
 
 
 def _act_lookup(key, x):
@@ -508,10 +521,11 @@ def _act_lookup(key, x):
     cache = _act_caches.get(tid)
     ent = cache.get(key) if cache else None
     if ent is not None:
-        rin, ver_in, y, ver_out, epoch, needs_grad = ent
+        rin, ver_in, y, ver_out, epoch, needs_grad, region = ent
         # (requires_grad can be switched on a leaf between two sibling calls without touching its version counter: an output built
         # without a graph must not be handed to a call that needs one, nor the reverse)
-        if rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch.get(tid, 0) and needs_grad == x.requires_grad:
+        if (rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch.get(tid, 0) and needs_grad == x.requires_grad
+                and region is _region()):
             return y
     return None
 
@@ -525,7 +539,7 @@ def _act_store(key, x, y):
     cache = _act_caches.get(tid)
     if cache is None:
         cache = _act_caches[tid] = {}
-    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch.get(tid, 0), x.requires_grad)
+    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch.get(tid, 0), x.requires_grad, _region())
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
@@ -633,10 +647,12 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
 #        value_states = SymQuantizer.apply(value_states, clip_v, kv_bits, False)
 #    are two launches forward and two backward on tensors of one shape.  With the call site UNTOUCHED: every QuantizeLinear
 #    notes its output (a weak reference, per thread); when SymQuantizer.apply receives such an output and the very next noted
-#    output has the same shape / dtype / device (K, then V), both are fake-quantized in ONE launch (the quantize_kv path), K's
-#    result is returned and V's is kept for the apply call that follows -- which must present that very tensor, unmodified, with
-#    the same clip / bits / grad mode / autocast state and no fake-quant backward in between; anything else discards it (the
-#    speculation then cost one tensor's forward, nothing else: a V result nobody asks for simply never receives a gradient).
+#    output has the same shape / dtype / device (K, then V), both are fake-quantized in ONE forward launch, K's result is
+#    returned and V's is kept -- as plain data, outside any graph -- for the apply call that follows, which must present that very
+#    tensor, unmodified, with the same clip / bits / grad mode / autocast state and no fake-quant backward in between; anything else
+#    discards it (the speculation then cost one tensor's forward, nothing else).  K and V each get their OWN autograd node over
+#    their own side buffer (two backward launches, as in the reference): a node over both -- what the explicit quantize_kv() call
+#    builds, where both results are certainly wanted -- would tie V's producer into K's graph before anyone asked for V.
 #    The decision depends only on the call sequence, so a checkpointed forward and its recompute build the same graph.
 #    Results and gradients are bit-identical to the two calls (tests/test_tiny_llama.py, tests/test_gpu_features.py).
 #    LLMQAT_AMD_PAIR_KV=0 / pair_kv_hooks(False) turn it off.
@@ -657,15 +673,15 @@ def _note_output(out):
         rec = _tls.outs = []
     if len(rec) >= 4:
         del rec[0]
-    rec.append((weakref.ref(out), out._version))
+    rec.append((weakref.ref(out), out._version, _region()))
 
 
 def _kv_state(clip_val, num_bits):
-    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops._semantics, _bwd_epoch.get(threading.get_ident(), 0))
+    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops._semantics, _bwd_epoch.get(threading.get_ident(), 0), _region())
 
 
 _kv_off = set()   # call signatures whose speculation was thrown away once: they stop pairing
-_kv_stash = {}    # forward thread id -> (weakref(V), version, V's result, state, signature): the pending half of a K+V launch
+_kv_stash = {}    # forward thread id -> (weakref(V), version, (V's result, its side buffer, rows, cols, clip), state, signature): the pending half of a K+V launch
 
 
 def _kv_discard(tid):
@@ -687,11 +703,12 @@ def _kv_hook(x, clip_val, num_bits):
     tid = threading.get_ident()
     stash = _kv_stash.get(tid)
     if stash is not None:
-        ref, ver, vq, state, sig = stash
+        ref, ver, vres, state, sig = stash
         if ref() is x and ver == x._version and state == _kv_state(clip_val, num_bits):
             del _kv_stash[tid]
             _count("kv_pair_hit")
-            return vq   # V: quantized together with K a moment ago
+            vq, side_v, rows_v, cols, clip = vres   # V: quantized together with K a moment ago; its autograd node is built only now
+            return vq if side_v is None else _PrecomputedAct.apply(x, vq, side_v, rows_v, cols, clip)
         _kv_discard(tid)
     rec = getattr(_tls, "outs", None)
     if not rec:
@@ -700,6 +717,9 @@ def _kv_hook(x, clip_val, num_bits):
         if rec[i][0]() is x:
             if rec[i][1] != x._version:
                 return None
+            region = _region()
+            if rec[i][2] is not region or rec[i + 1][2] is not region:
+                return None     # K's or V's projection ran in another saved-tensor-hooks region (see _region)
             v, vver = rec[i + 1][0](), rec[i + 1][1]
             if (v is None or v is x or vver != v._version or v.shape != x.shape or v.dtype != x.dtype or v.device != x.device
                     or not v.is_contiguous() or not x.is_contiguous() or v.requires_grad != x.requires_grad):
@@ -714,9 +734,13 @@ def _kv_hook(x, clip_val, num_bits):
             if res is None:
                 return None
             _count("kv_pair_launch")
-            kq, vq = _PairNode.apply(x, v, res, (lo, hi)) if need else (res[0], res[1])
-            _kv_stash[tid] = (weakref.ref(v), v._version, vq, _kv_state(clip_val, num_bits), sig)
-            return kq
+            # One launch forward, but NOT one autograd node: until the V call arrives, V's result is plain data (no graph refers to the
+            # tensor V), so a guess that turns out wrong leaves nothing behind -- in particular it cannot make V's producer reachable from
+            # a loss that never uses V (a checkpointed producer would be recomputed and hand ZERO gradients to its parameters where the
+            # reference leaves None: tests/test_gpu_random_programs.py).  Each of K and V gets its own node over its own side buffer.
+            kq, vq, side_k, side_v, rows_k, rows_v, cols = res
+            _kv_stash[tid] = (weakref.ref(v), v._version, (vq, side_v if need else None, rows_v, cols, (lo, hi)), _kv_state(clip_val, num_bits), sig)
+            return _PrecomputedAct.apply(x, kq, side_k, rows_k, cols, (lo, hi)) if need else kq
     return None
 
 
@@ -775,13 +799,16 @@ class _ReuseQuantizedWeight(torch.autograd.Function):
 
 
 class _PrecomputedAct(torch.autograd.Function):
-    """Autograd node over an activation that a paired launch has already fake-quantized (weight cache on): saves exactly
-    what _SymQuantizerOperand saves in mask mode (the side buffer), so a checkpointed forward that pairs and its recompute
-    that does not (the weight then comes from the cache) record the same tensors."""
+    """Autograd node over ONE tensor that a multi-tensor launch has already fake-quantized: forward launches nothing, backward is that
+    tensor's own STE launch.  Used where the tensors of a launch must NOT share a node: with the weight cache on (it saves exactly what
+    _SymQuantizerOperand saves in mask mode, so a checkpointed forward that pairs and its recompute that does not record the same
+    tensors), and for the K / V speculation at the unchanged hooks (point 7: a V result nobody asks for must leave no trace in the graph).
+    y may be the reference's fp32 result under autocast (then fp32 gradients come back: the wide backward)."""
 
     @staticmethod
     def forward(ctx, x, y, side, rows, cols, clip):
         ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_tid = (rows, cols), clip, x.dtype, threading.get_ident()
+        ctx.wide = y.dtype != x.dtype
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side)
         return y.view_as(y)
@@ -795,6 +822,8 @@ class _PrecomputedAct(torch.autograd.Function):
         (side,) = ctx.saved_tensors
         lo, hi = ctx.clip
         rows, cols = ctx.rows_cols
+        if ctx.wide:
+            return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.dtype), None, None, None, None, None
         g = grad_output if grad_output.dtype == ctx.dtype else grad_output.to(ctx.dtype)
         return ops.train_backward(g, side, rows, cols, lo, hi), None, None, None, None, None
 

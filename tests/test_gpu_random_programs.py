@@ -1,6 +1,8 @@
 """GPU tier: RANDOM PROGRAMS over the drop-in -- a generator builds a small graph out of QuantizeLinear layers (random w_bits incl. 1 / 2 /
 32, a_bits incl. off, Sym / Asym, layerwise flags), KV-hook style SymQuantizer.apply calls, elementwise glue, no_grad regions, tensors that
-do or do not require grad, then backpropagates a random loss -- and runs it twice: on the live eager chain (tiny_llama.EagerQuant over
+do or do not require grad, widths that the vector kernels serve and widths they do not, some steps under activation checkpointing, then
+backpropagates a random loss -- and runs it twice, the drop-in under a random configuration (backward mode, conservative, weight cache,
+K/V pairing, in-place weight gradients: none of which may change a result): on the live eager chain (tiny_llama.EagerQuant over
 oracle/eager_chain.py, plus the 1-/2-bit branch's op chain) and on the drop-in at default settings.
 
 What must hold for every program: the same outputs bit for bit; the same set of tensors receiving a gradient; with the shared activation
@@ -20,7 +22,6 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiny_llama as TL  # noqa: E402
 
-D = 64
 PROGRAMS = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "60"))
 
 
@@ -40,7 +41,7 @@ class EagerLowBitLinear(nn.Linear):
         return F.linear(x, w)
 
 
-def make_module(Q, eager, cfg):
+def make_module(Q, eager, cfg, D):
     from oracle import eager_chain as E
     w_bits, a_bits, sym, alw, wlw, seed = cfg
     if eager and w_bits < 3:
@@ -73,18 +74,29 @@ def gen_program(rng):
             steps.append((kind, rng.randrange(n_t), rng.randrange(n_t)))
         n_t += 1
     loss = [(i, rng.choice([1.0, 2.0, -0.5])) for i in range(len(inputs), n_t) if rng.random() < 0.6] or [(n_t - 1, 1.0)]
-    return mods, inputs, steps, loss, rng.random() < 0.5
+    # how the drop-in is configured for this program (results may not depend on any of it) + shape of the data
+    settings = dict(width=rng.choice([64, 64, 100, 264]), three_d=rng.random() < 0.7, backward_mode=rng.choice(["mask", "mask", "bounds", "plain"]),
+                    conservative=rng.random() < 0.15, weight_cache=rng.choice([None, None, "step", "persistent"]),
+                    checkpoint=rng.choice([None, None, "reentrant", "nonreentrant"]), pair_kv=rng.random() < 0.85, inplace=rng.random() < 0.85)
+    return mods, inputs, steps, loss, rng.random() < 0.5, settings
 
 
 def run_program(Q, eager, prog):
-    mods_cfg, inputs, steps, loss, autocast = prog
-    mods = [make_module(Q, eager, c) for c in mods_cfg]
-    ts = [(torch.randn(2, 7, D, generator=torch.Generator().manual_seed(seed)) * 1.5).cuda().bfloat16().requires_grad_(g) for g, seed in inputs]
+    from torch.utils.checkpoint import checkpoint
+    mods_cfg, inputs, steps, loss, autocast, cfg = prog
+    D = cfg["width"]
+    mods = [make_module(Q, eager, c, D) for c in mods_cfg]
+    shape = (2, 7, D) if cfg["three_d"] else (11, D)
+    ts = [(torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 1.5).cuda().bfloat16().requires_grad_(g) for g, seed in inputs]
     n_in = len(ts)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-        for st in steps:
+        for k, st in enumerate(steps):
             if st[0] == "linear":
-                ts.append(mods[st[1]](ts[st[2]].to(torch.bfloat16)))
+                x = ts[st[2]].to(torch.bfloat16)
+                if cfg["checkpoint"] and k % 3 == 0 and torch.is_grad_enabled():   # (both runs checkpoint the same steps)
+                    ts.append(checkpoint(mods[st[1]], x, use_reentrant=cfg["checkpoint"] == "reentrant"))
+                else:
+                    ts.append(mods[st[1]](x))
             elif st[0] == "nograd_linear":
                 with torch.no_grad():
                     ts.append(mods[st[1]](ts[st[2]].to(torch.bfloat16)))
@@ -106,11 +118,24 @@ def check_program(seed, share):
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
     prog = gen_program(random.Random(seed))
+    cfg = prog[-1]
     llm_qat_amd.reset_learned_state()
     want_o, want_g = run_program(TL.EagerQuant(), True, prog)
-    llm_qat_amd.share_activation_quant(share)
-    llm_qat_amd.reset_learned_state()
-    got_o, got_g = run_program(UQ, False, prog)
+    prev_mode = llm_qat_amd.get_backward_mode()
+    try:
+        llm_qat_amd.conservative(cfg["conservative"])
+        if not cfg["conservative"]:
+            llm_qat_amd.share_activation_quant(share)
+            llm_qat_amd.pair_kv_hooks(cfg["pair_kv"])
+            llm_qat_amd.inplace_weight_grad(cfg["inplace"])
+            llm_qat_amd.enable_weight_quant_cache(cfg["weight_cache"] is not None, persistent=cfg["weight_cache"] == "persistent")
+        llm_qat_amd.set_backward_mode(cfg["backward_mode"])
+        llm_qat_amd.reset_learned_state()
+        got_o, got_g = run_program(UQ, False, prog)
+    finally:
+        llm_qat_amd.set_backward_mode(prev_mode)
+        llm_qat_amd.conservative(False)
+        llm_qat_amd.enable_weight_quant_cache(False)
     tag = f"program seed={seed} share={share}: {prog}"
     assert len(want_o) == len(got_o)
     for i, (a, b) in enumerate(zip(want_o, got_o)):
@@ -119,7 +144,7 @@ def check_program(seed, share):
         assert (a is None) == (b is None), f"gradient {i} present in one run only, {tag}"
         if a is None:
             continue
-        if share:   # association order of bf16 sums may differ where a shared input has further consumers: same support, close in a norm
+        if share and not cfg["conservative"]:   # association order of bf16 sums may differ where a shared input has further consumers: same support, close in a norm
             assert torch.equal(a == 0, b == 0) or float((a.float() - b.float()).abs().max()) <= 2 ** -5 * float(a.float().abs().max() + 1e-6), f"gradient {i} of {tag}"
             assert float((a.float() - b.float()).norm()) <= 2 ** -5 * float(a.float().norm() + 1e-6), f"gradient {i} of {tag}"
         else:

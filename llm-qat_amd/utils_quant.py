@@ -622,7 +622,11 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
 
     in ONE launch forward and one backward (K and V are [bsz, q_len, hidden] tensors of the same dtype: same row
     length, same launch shape).  Results and gradients are bit-identical to the two calls; under autocast both come
-    back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served."""
+    back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served.
+    Both results share ONE autograd node (they are both wanted: that is what calling this says).  Two things follow that the two
+    separate calls do not have: a tensor hook on a result that is then never used is called with None (PyTorch's way with an unused
+    output of a multi-output node), and the SAME tensor passed as both K and V gets its two gradients summed at this node's position in
+    the accumulation order (same sum, possibly another association)."""
     k, v = key_states, value_states
     if type(num_bits) is not int:
         num_bits = ops.bits_arg(num_bits)

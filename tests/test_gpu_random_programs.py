@@ -63,13 +63,23 @@ def gen_program(rng):
     inputs = [(rng.random() < 0.8, rng.randrange(10 ** 6)) for _ in range(rng.randint(1, 2))]
     steps, n_t = [], len(inputs)
     for _ in range(rng.randint(3, 12)):
-        kind = rng.choices(["linear", "hook", "scale", "add", "nograd_linear"], [6, 3, 1, 1, 1])[0]
+        kind = rng.choices(["linear", "hook", "scale", "add", "nograd_linear", "kv"], [6, 3, 1, 1, 1, 1])[0]
         if kind in ("linear", "nograd_linear"):
             steps.append((kind, rng.randrange(len(mods)), rng.randrange(n_t)))
         elif kind == "hook":
             steps.append((kind, rng.choice([1, 2, 4, 8]), rng.randrange(n_t), rng.choice([(-2.0, 2.0), (-2.0, 2.0), (-1.0, 1.5)])))
         elif kind == "scale":
             steps.append((kind, rng.choice([0.5, 1.5, -1.0]), rng.randrange(n_t)))
+        elif kind == "kv":    # the explicit two-tensor call; appends TWO tensors
+            a = rng.randrange(n_t)
+            b = rng.randrange(n_t)
+            if a == b:      # (K and V are different tensors in any model; one tensor passed as both gets the same values, with its two
+                b = (a + 1) % n_t if n_t > 1 else a      # gradients summed in the pair node's order rather than as two separate nodes)
+            if a == b:
+                steps.append(("hook", rng.choice([2, 4, 8]), a, (-2.0, 2.0)))
+            else:
+                steps.append((kind, rng.choice([2, 4, 8]), a, b, rng.random() < 0.8))
+                n_t += 1
         else:
             steps.append((kind, rng.randrange(n_t), rng.randrange(n_t)))
         n_t += 1
@@ -77,7 +87,8 @@ def gen_program(rng):
     # how the drop-in is configured for this program (results may not depend on any of it) + shape of the data
     settings = dict(width=rng.choice([64, 64, 100, 264]), three_d=rng.random() < 0.7, backward_mode=rng.choice(["mask", "mask", "bounds", "plain"]),
                     conservative=rng.random() < 0.15, weight_cache=rng.choice([None, None, "step", "persistent"]),
-                    checkpoint=rng.choice([None, None, "reentrant", "nonreentrant"]), pair_kv=rng.random() < 0.85, inplace=rng.random() < 0.85)
+                    checkpoint=rng.choice([None, None, "reentrant", "nonreentrant"]), pair_kv=rng.random() < 0.85, inplace=rng.random() < 0.85,
+                    second_backward=rng.random() < 0.2, grad_hooks=rng.random() < 0.3)
     return mods, inputs, steps, loss, rng.random() < 0.5, settings
 
 
@@ -104,13 +115,31 @@ def run_program(Q, eager, prog):
                 ts.append(Q.SymQuantizer.apply(ts[st[2]], torch.tensor(st[3]), st[1], False))
             elif st[0] == "scale":
                 ts.append(ts[st[2]] * st[1])
+            elif st[0] == "kv":
+                k, v = ts[st[2]], ts[st[3]]
+                ck, cv = torch.tensor([-2.0, 2.0]), torch.tensor([-2.0, 2.0] if st[4] else [-1.0, 1.5])
+                if getattr(Q, "quantize_kv", None) is not None and not eager:
+                    kq, vq = Q.quantize_kv(k, v, ck, cv, st[1])
+                else:
+                    kq, vq = Q.SymQuantizer.apply(k, ck, st[1], False), Q.SymQuantizer.apply(v, cv, st[1], False)
+                ts += [kq, vq]
             else:
                 ts.append(ts[st[1]].float() + ts[st[2]].float())
+    seen = [None] * len(ts)
+    if cfg["grad_hooks"]:     # tensor hooks see the gradient of an intermediate exactly as in the reference (recorded per tensor: the ORDER in
+        for i, t in enumerate(ts):   # which hooks fire follows the nodes' creation order, which a two-output node legitimately changes; a hook
+            if i >= n_in and t.requires_grad:   # on an UNUSED result of quantize_kv() is called with None -- PyTorch's way with an unused output of
+                def hook(g, i=i):               # a multi-output node -- where the reference's separate node never runs: not recorded)
+                    if g is not None:
+                        seen[i] = g.detach().clone() if seen[i] is None else seen[i] + g.detach()
+                t.register_hook(hook)
     total = sum(ts[i].float().sum() * w for i, w in loss)
     if total.requires_grad:
-        total.backward()
+        total.backward(retain_graph=cfg["second_backward"])
+        if cfg["second_backward"] and not cfg["checkpoint"]:
+            total.backward()
     outs = [t.detach() for t in ts[n_in:]]
-    grads = [t.grad for t in ts[:n_in]] + [m.weight.grad for m in mods]
+    grads = [t.grad for t in ts[:n_in]] + [m.weight.grad for m in mods] + seen
     return outs, grads
 
 

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiny_llama as TL  # noqa: E402
 
 PROGRAMS = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "60"))
+SEED0 = int(os.environ.get("LLMQAT_RANDOM_SEED0", "0"))
 
 
 class EagerLowBitLinear(nn.Linear):
@@ -185,7 +186,7 @@ def test_random_programs_match_the_eager_chain(share):
     import llm_qat_amd
     llm_qat_amd.set_semantics("device_eager")
     try:
-        for seed in range(PROGRAMS):
+        for seed in range(SEED0, SEED0 + PROGRAMS):
             check_program(seed, share)
     finally:
         llm_qat_amd.share_activation_quant(True)

@@ -42,18 +42,18 @@ class EagerLowBitLinear(nn.Linear):
         return F.linear(x, w)
 
 
-def make_module(Q, eager, cfg, D):
-    from oracle import eager_chain as E
+def make_module(Q, eager, cfg, D, device="cuda"):
     w_bits, a_bits, sym, alw, wlw, seed = cfg
-    if eager and w_bits < 3:
+    if eager and w_bits < 3 and not hasattr(Q, "REAL_REFERENCE"):   # (tiny_llama.EagerQuant has no 1-/2-bit branch; the real reference has)
+        from oracle import eager_chain as E
         m = EagerLowBitLinear(D, D, w_bits, a_bits, sym, alw, wlw, E)
     elif eager:
         m = Q.QuantizeLinear(D, D, symmetric=sym, w_bits=w_bits, a_bits=a_bits, act_layerwise=alw, weight_layerwise=wlw)
     else:
         m = Q.QuantizeLinear(D, D, symmetric=sym, w_bits=w_bits, a_bits=a_bits, act_layerwise=alw, weight_layerwise=wlw)
-    m = m.cuda().bfloat16()
+    m = m.to(device).bfloat16()
     with torch.no_grad():
-        m.weight.copy_((torch.randn(D, D, generator=torch.Generator().manual_seed(seed)) * 0.3).cuda().bfloat16())
+        m.weight.copy_((torch.randn(D, D, generator=torch.Generator().manual_seed(seed)) * 0.3).to(device).bfloat16())
         m.weight[1, 2] = 2.5
     return m
 
@@ -93,15 +93,15 @@ def gen_program(rng):
     return mods, inputs, steps, loss, rng.random() < 0.5, settings
 
 
-def run_program(Q, eager, prog):
+def run_program(Q, eager, prog, device="cuda"):
     from torch.utils.checkpoint import checkpoint
     mods_cfg, inputs, steps, loss, autocast, cfg = prog
     D = cfg["width"]
-    mods = [make_module(Q, eager, c, D) for c in mods_cfg]
+    mods = [make_module(Q, eager, c, D, device) for c in mods_cfg]
     shape = (2, 7, D) if cfg["three_d"] else (11, D)
-    ts = [(torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 1.5).cuda().bfloat16().requires_grad_(g) for g, seed in inputs]
+    ts = [(torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 1.5).to(device).bfloat16().requires_grad_(g) for g, seed in inputs]
     n_in = len(ts)
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast and device == "cuda"):
         for k, st in enumerate(steps):
             if st[0] == "linear":
                 x = ts[st[2]].to(torch.bfloat16)

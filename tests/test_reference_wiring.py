@@ -111,3 +111,63 @@ def test_real_reference_model_on_the_dropin_cpu_path_equals_the_real_reference(w
         llm_qat_amd.reset_learned_state()
         for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
             del sys.modules[name]
+
+
+def test_random_programs_on_the_cpu_path_equal_the_live_reference():
+    """tests/test_gpu_random_programs.py's generator (graphs of QuantizeLinear layers incl. the 1-/2-bit branches, hook-style SymQuantizer.apply
+    calls, glue, no_grad regions, checkpointed steps, tensor hooks, a second backward), run on CPU tensors against the REAL reference's own
+    classes, live: the drop-in's opt-in CPU-tensor path with its host logic at random settings.  Sharing off: every output and gradient bit
+    for bit; sharing on: outputs bit for bit, gradients up to the association order of bf16 sums (utils_quant.py point 1)."""
+    import random
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_random_programs as RP
+    for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+        del sys.modules[name]
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        import models.utils_quant as R
+    finally:
+        sys.path.remove(REF)
+    R.REAL_REFERENCE = True
+    n = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "80"))
+    llm_qat_amd.allow_cpu_tensors(True)
+    try:
+        for seed in range(n):
+            for share in (False, True):
+                prog = RP.gen_program(random.Random(seed))
+                cfg = prog[-1]
+                llm_qat_amd.reset_learned_state()
+                want_o, want_g = RP.run_program(R, True, prog, device="cpu")
+                prev = llm_qat_amd.get_backward_mode()
+                try:
+                    llm_qat_amd.conservative(cfg["conservative"])
+                    if not cfg["conservative"]:
+                        llm_qat_amd.share_activation_quant(share)
+                        llm_qat_amd.enable_weight_quant_cache(cfg["weight_cache"] is not None, persistent=cfg["weight_cache"] == "persistent")
+                    llm_qat_amd.set_backward_mode(cfg["backward_mode"])
+                    llm_qat_amd.reset_learned_state()
+                    got_o, got_g = RP.run_program(UQ, False, prog, device="cpu")
+                finally:
+                    llm_qat_amd.set_backward_mode(prev)
+                    llm_qat_amd.conservative(False)
+                    llm_qat_amd.enable_weight_quant_cache(False)
+                tag = f"program seed={seed} share={share}: {prog}"
+                assert len(want_o) == len(got_o)
+                for i, (a, b) in enumerate(zip(want_o, got_o)):
+                    assert a.dtype == b.dtype and torch.equal(a.nan_to_num(), b.nan_to_num()), f"output {i} of {tag}"
+                for i, (a, b) in enumerate(zip(want_g, got_g)):
+                    assert (a is None) == (b is None), f"gradient {i} present in one run only, {tag}"
+                    if a is None:
+                        continue
+                    if share and not cfg["conservative"]:
+                        assert float((a.float() - b.float()).norm()) <= 2 ** -5 * float(a.float().norm() + 1e-6), f"gradient {i} of {tag}"
+                    else:
+                        assert torch.equal(a, b), f"gradient {i} of {tag}"
+    finally:
+        llm_qat_amd.allow_cpu_tensors(False)
+        llm_qat_amd.reset_learned_state()
+        for name in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+            del sys.modules[name]

@@ -570,14 +570,14 @@ def pair_operands(flag=True):
 
 
 class _PairNode(torch.autograd.Function):
-    """Autograd node over the results of one ops.pair_forward launch (weight and input of a QuantizeLinear)."""
+    """Autograd node over the results of one ops.pair_forward launch: weight and input of a QuantizeLinear, whose two results have one
+    consumer, that module's F.linear, and so live or die together.  (K and V of the KV hooks share a forward launch but never a node.)"""
 
     @staticmethod
     def forward(ctx, weight, input, res, clip=(-2.0, 2.0), weight_first=False):
         wq, xq, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
         ctx.dtype, ctx.clip, ctx.fq_tid = weight.dtype, clip, threading.get_ident()
         ctx.inplace_w = bool(weight_first)  # tensor 0 is a QuantizeLinear's weight: its gradient may be handed on by reference
-        ctx.wide = wq.dtype != weight.dtype  # fp32 results under autocast (the K / V hooks): fp32 gradients come back
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
         # (wq / xq are fresh tensors of the launch that nothing else refers to: they become this node's outputs as they are)
@@ -597,12 +597,6 @@ class _PairNode(torch.autograd.Function):
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lo, hi = ctx.clip
         side_w, side_x = ctx.saved_tensors
-        if ctx.wide:
-            gw, gx = (gw if need_w else None), (gx if need_x else None)
-            if gw is None and gx is None:
-                return None, None, None, None, None
-            ow, ox = ops.pair_backward_wide(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, ctx.dtype)
-            return ow, ox, None, None, None
         if need_w and gw is not None and gw.dtype != ctx.dtype:
             gw, inplace_w = gw.to(ctx.dtype), ctx.inplace_w and _INPLACE_WGRAD   # a fresh tensor of our own
         elif not need_w:
@@ -620,13 +614,12 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
         key_states   = self.act_quantizer_k.apply(key_states,   self.act_clip_val_k, self.kv_bits, False)
         value_states = self.act_quantizer_v.apply(value_states, self.act_clip_val_v, self.kv_bits, False)
 
-    in ONE launch forward and one backward (K and V are [bsz, q_len, hidden] tensors of the same dtype: same row
-    length, same launch shape).  Results and gradients are bit-identical to the two calls; under autocast both come
-    back in fp32, as the reference's do.  Falls back to the two calls whenever the pair is not served.
-    Both results share ONE autograd node (they are both wanted: that is what calling this says).  Two things follow that the two
-    separate calls do not have: a tensor hook on a result that is then never used is called with None (PyTorch's way with an unused
-    output of a multi-output node), and the SAME tensor passed as both K and V gets its two gradients summed at this node's position in
-    the accumulation order (same sum, possibly another association)."""
+    in ONE forward launch (K and V are [bsz, q_len, hidden] tensors of the same dtype: same row length, same launch shape).
+    Results and gradients are bit-identical to the two calls; under autocast both come back in fp32, as the reference's do.  Falls back
+    to the two calls whenever the pair is not served.  Each result has its OWN autograd node over its own side buffer (two backward
+    launches, as in the reference): one node over both would tie V's producer into K's graph, and a result that is then never used
+    would drag a dead branch into the backward pass (a checkpointed producer would be recomputed and hand zero gradients to its parameters
+    where the reference leaves None; a hook on the unused result would be called with None) -- tests/test_gpu_random_programs.py."""
     k, v = key_states, value_states
     if type(num_bits) is not int:
         num_bits = ops.bits_arg(num_bits)
@@ -639,9 +632,9 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
         need_k, need_v = grad and k.requires_grad, grad and v.requires_grad
         res = ops.pair_forward(k, v, num_bits, num_bits, lo, hi, need_k, need_v, wide=True)
         if res is not None:
-            if need_k or need_v:
-                return _PairNode.apply(k, v, res, (lo, hi))
-            return res[0], res[1]
+            kq, vq, side_k, side_v, rows_k, rows_v, cols = res
+            return (_PrecomputedAct.apply(k, kq, side_k, rows_k, cols, (lo, hi)) if need_k else kq,
+                    _PrecomputedAct.apply(v, vq, side_v, rows_v, cols, (lo, hi)) if need_v else vq)
     return (SymQuantizer.apply(k, clip_val_k, num_bits, False), SymQuantizer.apply(v, clip_val_v, num_bits, False))
 
 
@@ -655,8 +648,8 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
 #    returned and V's is kept -- as plain data, outside any graph -- for the apply call that follows, which must present that very
 #    tensor, unmodified, with the same clip / bits / grad mode / autocast state and no fake-quant backward in between; anything else
 #    discards it (the speculation then cost one tensor's forward, nothing else).  K and V each get their OWN autograd node over
-#    their own side buffer (two backward launches, as in the reference): a node over both -- what the explicit quantize_kv() call
-#    builds, where both results are certainly wanted -- would tie V's producer into K's graph before anyone asked for V.
+#    their own side buffer (two backward launches, as in the reference; the explicit quantize_kv() call does the same): a node over
+#    both would tie V's producer into K's graph -- before anyone asked for V, or although its result ends up unused.
 #    The decision depends only on the call sequence, so a checkpointed forward and its recompute build the same graph.
 #    Results and gradients are bit-identical to the two calls (tests/test_tiny_llama.py, tests/test_gpu_features.py).
 #    LLMQAT_AMD_PAIR_KV=0 / pair_kv_hooks(False) turn it off.

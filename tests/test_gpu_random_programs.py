@@ -74,13 +74,8 @@ def gen_program(rng):
         elif kind == "kv":    # the explicit two-tensor call; appends TWO tensors
             a = rng.randrange(n_t)
             b = rng.randrange(n_t)
-            if a == b:      # (K and V are different tensors in any model; one tensor passed as both gets the same values, with its two
-                b = (a + 1) % n_t if n_t > 1 else a      # gradients summed in the pair node's order rather than as two separate nodes)
-            if a == b:
-                steps.append(("hook", rng.choice([2, 4, 8]), a, (-2.0, 2.0)))
-            else:
-                steps.append((kind, rng.choice([2, 4, 8]), a, b, rng.random() < 0.8))
-                n_t += 1
+            steps.append((kind, rng.choice([2, 4, 8]), a, b, rng.random() < 0.8))   # (a == b happens: one tensor as both K and V)
+            n_t += 1
         else:
             steps.append((kind, rng.randrange(n_t), rng.randrange(n_t)))
         n_t += 1
@@ -127,12 +122,11 @@ def run_program(Q, eager, prog, device="cuda"):
             else:
                 ts.append(ts[st[1]].float() + ts[st[2]].float())
     seen = [None] * len(ts)
-    if cfg["grad_hooks"]:     # tensor hooks see the gradient of an intermediate exactly as in the reference (recorded per tensor: the ORDER in
-        for i, t in enumerate(ts):   # which hooks fire follows the nodes' creation order, which a two-output node legitimately changes; a hook
-            if i >= n_in and t.requires_grad:   # on an UNUSED result of quantize_kv() is called with None -- PyTorch's way with an unused output of
-                def hook(g, i=i):               # a multi-output node -- where the reference's separate node never runs: not recorded)
-                    if g is not None:
-                        seen[i] = g.detach().clone() if seen[i] is None else seen[i] + g.detach()
+    if cfg["grad_hooks"]:     # tensor hooks see the gradient of an intermediate exactly as in the reference (recorded per tensor)
+        for i, t in enumerate(ts):
+            if i >= n_in and t.requires_grad:
+                def hook(g, i=i):
+                    seen[i] = g.detach().clone() if seen[i] is None else seen[i] + g.detach()
                 t.register_hook(hook)
     total = sum(ts[i].float().sum() * w for i, w in loss)
     if total.requires_grad:

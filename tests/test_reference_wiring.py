@@ -132,10 +132,10 @@ def test_random_programs_on_the_cpu_path_equal_the_live_reference():
     finally:
         sys.path.remove(REF)
     R.REAL_REFERENCE = True
-    n = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "80"))
+    n, seed0 = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "80")), int(os.environ.get("LLMQAT_RANDOM_SEED0", "0"))
     llm_qat_amd.allow_cpu_tensors(True)
     try:
-        for seed in range(n):
+        for seed in range(seed0, seed0 + n):
             for share in (False, True):
                 prog = RP.gen_program(random.Random(seed))
                 cfg = prog[-1]

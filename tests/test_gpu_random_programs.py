@@ -180,8 +180,12 @@ def test_random_programs_match_the_eager_chain(share):
     import llm_qat_amd
     llm_qat_amd.set_semantics("device_eager")
     try:
+        progress = os.environ.get("LLMQAT_PROGRESS_FILE")    # long sweeps: a line every 500 programs, so that a watchdog sees the run alive
         for seed in range(SEED0, SEED0 + PROGRAMS):
             check_program(seed, share)
+            if progress and (seed + 1) % 500 == 0:
+                with open(progress, "a") as f:
+                    f.write(f"share={share} seed {seed + 1}\n")
     finally:
         llm_qat_amd.share_activation_quant(True)
         llm_qat_amd.set_semantics("cpu_eager")

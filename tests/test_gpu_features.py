@@ -851,6 +851,48 @@ def test_ddp_wrapped_model_step_is_unchanged(pkg):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kw", [{"gradient_as_bucket_view": True}, {"find_unused_parameters": True}, {"static_graph": True},
+                                {"gradient_as_bucket_view": True, "static_graph": True}], ids=lambda k: "+".join(k))
+def test_ddp_variants_match_the_bare_eager_model(pkg, kw):
+    """DDP's other modes around the drop-in -- gradients as views of the reducer's buckets (AccumulateGrad then writes INTO a bucket: the
+    in-place weight-gradient path must hand it a tensor it may take or add), unused-parameter detection, static graph, and a first step
+    under no_sync() with accumulation into existing .grad -- three steps, one rank over RCCL: losses and every parameter gradient equal
+    the bare model on the live eager chain (utils/kd_trainer.py:257-277 is the reference's outer loop)."""
+    from contextlib import nullcontext
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import tiny_llama as TL
+    import llm_qat_amd.utils_quant as UQ
+    dist = _one_rank_group()
+    try:
+        ids = TL.deterministic_batch().cuda()
+
+        def run(Q, wrap):
+            pkg.reset_learned_state()
+            m = TL.load_deterministic(TL.TinyLlama(Q, w_bits=4, a_bits=8, kv_bits=4).bfloat16()).cuda()
+            if wrap:
+                m = DDP(m, device_ids=[0], **kw)
+            losses = []
+            for step in range(3):
+                m.zero_grad(set_to_none=(step != 1))          # step 1 accumulates into step 0's gradients
+                with (m.no_sync() if (wrap and step == 0 and "static_graph" not in kw) else nullcontext()):
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        loss, _ = m(ids, labels=ids)
+                    loss.backward()
+                losses.append(loss.detach())
+            return losses, [p.grad.clone() for p in (m.module if wrap else m).parameters()]
+
+        pkg.set_semantics("device_eager")
+        want = run(TL.EagerQuant(), False)
+        pkg.stats(reset=True)
+        got = run(UQ, True)
+        assert all(torch.equal(a, b) for a, b in zip(want[0], got[0]))
+        assert all(torch.equal(a, b) for a, b in zip(want[1], got[1]))
+        assert pkg.stats().get("inplace_taken") == 3 * 14 and not any(k.startswith("inplace_refused") for k in pkg.stats())
+    finally:
+        pkg.set_semantics("cpu_eager")
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("autocast", [False, True])
 def test_torch_compile_traces_through_the_quantizers(pkg, autocast):
     """HF's `--torch_compile` (utils/kd_trainer.py:281-286): while Dynamo traces, the quantizers are torch.library

@@ -23,33 +23,29 @@ def refuse(x, what):
                        "(CPU tensors are served, with plain torch ops, only after llm_qat_amd.allow_cpu_tensors(True) / LLMQAT_AMD_CPU_TENSORS=1.)")
 
 
-def _per_row(reduce, x, layerwise):
+def _stat(x, layerwise, largest):
+    """The statistic one scale is made of, KEPT SMALL: shape [..., 1] (ndim <= 3), [d0, d1, 1, 1] (4-D) or 0-dim (layerwise), and left to
+    broadcast in the elementwise ops that follow.  The reference expands it to the input's shape first (:57, :67, :118-140); every element
+    then sees the same scalar operands either way, so the values are the same bit for bit, and the per-row part of the chain runs on
+    rows instead of on elements (what tests/test_cpu_tensors.py checks against the reference's own fixtures)."""
+    pick = torch.max if largest else torch.min
     if layerwise:
-        return reduce(x, None).expand_as(x)
+        return pick(x)                                   # :51 / :111-112
     if x.dim() <= 3:
-        return reduce(x, -1).expand_as(x)
+        return pick(x, dim=-1, keepdim=True)[0]          # :56 / :116-118
     if x.dim() == 4:
-        return reduce(x.view(x.shape[0], x.shape[1], -1), -1).unsqueeze(-1).expand_as(x)
+        return pick(x.view(x.shape[0], x.shape[1], -1), dim=-1, keepdim=True)[0].unsqueeze(-1)   # :63-66 / :127-139
     raise ValueError(f"fake-quant expects at most 4 dimensions, got {x.dim()}")   # :70
-
-
-def _amax(t, d):
-    return torch.max(t) if d is None else torch.max(t, dim=d, keepdim=True)[0]
-
-
-def _amin(t, d):
-    return torch.min(t) if d is None else torch.min(t, dim=d, keepdim=True)[0]
 
 
 def forward(kind, x, num_bits, layerwise):
     if kind == "sym":
-        top = _per_row(lambda t, d: _amax(torch.abs(t), d), x, layerwise)
-        s = (2 ** (num_bits - 1) - 1) / (top + 1e-6)
-        return torch.round(x * s).div(s + 1e-6)
-    lo = _per_row(_amin, x, layerwise)
-    alpha = _per_row(_amax, x, layerwise) - lo
+        s = (2 ** (num_bits - 1) - 1) / (_stat(torch.abs(x), layerwise, True) + 1e-6)    # int / Tensor: reciprocal() * int, per row
+        return torch.round(x * s).div(s + 1e-6)                                          # :72
+    beta = _stat(x, layerwise, False)
+    span = (_stat(x, layerwise, True) - beta) + 1e-8                                     # alpha + 1e-8, used twice (:144, :147)
     levels = 2 ** num_bits - 1
-    return torch.round((x - lo) / (alpha + 1e-8) * levels).div(levels) * (alpha + 1e-8) + lo
+    return torch.round((x - beta) / span * levels).div(levels) * span + beta
 
 
 def backward(grad_output, x, clip_val):

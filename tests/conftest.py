@@ -34,6 +34,24 @@ def pytest_sessionstart(session):
         print(f"[conftest] oracle build failed: {e!r}", file=sys.stderr)
 
 
+def experiment_module(*rel):
+    """A measurement library under tools/ (tools/qlinear, tools/int8_linear: experiments, not the product): import its Python wrapper,
+    build / load its .so, and SKIP the calling test -- never fail it -- when that is not possible.  The product's own tests never
+    come through here (tests/test_abi_and_host.py checks that the package does not reach into tools/)."""
+    import importlib.util
+    path = os.path.join(ROOT, *rel)
+    try:
+        spec = importlib.util.spec_from_file_location("_experiment_" + rel[-1].replace(".py", ""), path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+        if hasattr(mod, "lib"):
+            mod.lib()
+        return mod
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"experiment library {'/'.join(rel[:-1])} is not available ({e!r}): experiments are not part of the product build")
+
+
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests are skipped (not failed) where no GPU is visible, e.g. in the build container."""
     try:

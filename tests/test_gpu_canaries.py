@@ -189,11 +189,9 @@ def test_round2_entry_points_stay_inside_their_buffers(dtype, code, es):
 
 def test_qlinear_stays_inside_its_buffers():
     """the fused-GEMM experiment (tools/qlinear, not part of the product library) stays inside its buffers too"""
-    import os
-    import sys
+    from conftest import experiment_module
     from llm_qat_amd import _lib
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "qlinear"))
-    import qlinear as QX
+    QX = experiment_module("tools", "qlinear", "qlinear.py")   # skips when the experiment library is not available
     L, LQ = _lib.lib(), QX.lib()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -16,10 +16,22 @@ import torch.nn.functional as F
 
 from oracle import oracle as O
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "qlinear"))
-import qlinear as QX  # noqa: E402
+from conftest import experiment_module
 
 pytestmark = pytest.mark.gpu
+
+
+class _Lazy:
+    """tools/qlinear/qlinear.py, loaded on first use: the tests SKIP when the experiment library cannot be built or loaded"""
+    _mod = None
+
+    def __getattr__(self, name):
+        if _Lazy._mod is None:
+            _Lazy._mod = experiment_module("tools", "qlinear", "qlinear.py")
+        return getattr(_Lazy._mod, name)
+
+
+QX = _Lazy()
 
 
 def bits(t):
@@ -126,3 +138,54 @@ def test_unserved_shapes_return_none(ops):
     w = torch.randn(16, 100, device="cuda").to(torch.bfloat16)
     assert QX.qlinear_forward(x, w, 4, 8) is None                       # in_features % 64 != 0
     assert QX.qlinear_forward(x.float(), w.float(), 4, 8) is None       # bf16 only
+
+
+# ---- round 5: the second attempt (tools/qlinear/fq_qlinear_direct.hip): W direct-to-VGPR as the MFMA operand, x by LDS-DMA.  A measured
+# no-go like the first (profiles/r05_qlinear_direct_operand.json); what is pinned here is that the experiment is CORRECT.
+def _direct(x, w, ws=None, bk=64, mfma=32, ac=0, abl=0):
+    out = torch.full((x.shape[0], w.shape[0]), float("nan"), dtype=torch.bfloat16, device=x.device)
+    rc = QX.lib().fq_qlinear_direct_fwd(x.data_ptr(), w.data_ptr(), ws.data_ptr() if ws is not None else None, out.data_ptr(), x.shape[0], x.shape[1], w.shape[0],
+                                        bk, mfma, ac, abl, torch.cuda.current_stream().cuda_stream)
+    QX.check(rc, "fq_qlinear_direct_fwd")
+    return out
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("bk", [64, 128])
+@pytest.mark.parametrize("shape", [(128, 256, 384), (200, 300, 768), (77, 36, 512), (513, 260, 1152)])   # (tokens, out, in): every K remainder mod 3
+def test_direct_operand_kernel_exact_on_integer_data(ops, shape, bk, mfma):
+    """small integers: every partial sum is exact, so any accumulation order gives the same bits -- a wrong k re-mapping between the W
+    loads and the x fragment reads, a wrong source-side swizzle of the LDS-DMA, a swapped fragment map or a lost K-step would not"""
+    m, n, k = shape
+    if k // bk < 3:
+        pytest.skip("the pipeline needs three K-steps")
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = torch.randint(-3, 4, (m, k), generator=g, device="cuda").float()
+    w = torch.randint(-2, 3, (n, k), generator=g, device="cuda").float()
+    w[:, 0] += torch.arange(n, device="cuda") % 3
+    x[:, 1] += torch.arange(m, device="cuda") % 2
+    ref = (x @ w.t()).bfloat16()
+    for abl in (0, 10, 20):   # plain / `nt` / `sc1` W loads
+        got = _direct(x.bfloat16(), w.bfloat16(), bk=bk, mfma=mfma, abl=abl)
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (shape, bk, mfma, abl)
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("autocast", [False, True])
+def test_direct_operand_kernel_quantizes_w_like_the_product(ops, mfma, autocast):
+    """W fake-quantized in registers on its way into the MFMA == the GEMM over the product's own fq_sym_fwd(W): with integer x the only
+    difference left is the fp32 accumulation order"""
+    m, n, k = 192, 320, 11008
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = (torch.randn(n, k, generator=g, device="cuda") * 0.02).bfloat16()
+    x = torch.randint(-2, 3, (m, k), generator=g, device="cuda").bfloat16()
+    ws = ops.sym_row_scales(w, 4, False, autocast=autocast)
+    if autocast:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            wq = ops.sym_forward_autocast(w, 4, False, wide=False)[0]
+    else:
+        wq = ops.sym_quantize(w, 4)
+    got = _direct(x, w, ws=ws, bk=64, mfma=mfma, ac=int(autocast)).double()
+    ref = x.double() @ wq.double().t()
+    tol = 2.0 ** -8 * ref.abs() + k * 2.0 ** -24 * (x.double().abs() @ wq.double().abs().t())
+    assert bool(((got - ref).abs() <= tol).all())

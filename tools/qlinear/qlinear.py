@@ -14,8 +14,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(HERE, "fq_qlinear.hip")
+SRC_DIRECT = os.path.join(HERE, "fq_qlinear_direct.hip")   # round 5: W direct-to-VGPR as the MFMA operand, x by LDS-DMA
 LIB = os.path.join(HERE, "libfq_qlinear_exp.so")
-_DEPS = [SRC] + [os.path.join(ROOT, "llm-qat_amd", "csrc", f) for f in ("fq_device.h", "fq_kernels.h", "fq_launch.h")] + [
+_DEPS = [SRC, SRC_DIRECT] + [os.path.join(ROOT, "llm-qat_amd", "csrc", f) for f in ("fq_device.h", "fq_kernels.h", "fq_launch.h")] + [
     os.path.join(ROOT, "include", "llmqat_fakequant.h")]
 _lib = None
 
@@ -25,7 +26,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc if os.path.exists(hipcc) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-           "-fvisibility=hidden", "-fPIC", "-shared", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-function", "-o", LIB, SRC]
+           "-fvisibility=hidden", "-fPIC", "-shared", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-function", "-o", LIB, SRC, SRC_DIRECT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -41,6 +42,8 @@ def lib():
         L.fq_qlinear_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp, vp, i32, vp]
         L.fq_qlinear_fwd.restype = i32
         L.fq_qlinear_last_error.restype = ctypes.c_char_p
+        L.fq_qlinear_direct_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, vp]
+        L.fq_qlinear_direct_fwd.restype = i32
         _lib = L
     return _lib
 

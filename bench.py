@@ -1020,7 +1020,7 @@ def main(argv=None):
         "config": {"workload": "SymQuantizer fwd + STE bwd, W4 on weight-style [4096,11008] + A8 on activation-style "
                                "[4096,11008], bf16, clip [-2,2] (LLaMA-7B W4-A8 down_proj shapes, configs[1])",
                    "elements_per_step": elems_step, "buffer_sets": wl.nsets, "parallelism": "replicas" if world > 1 else "1gpu",
-                   "semantics": "cpu_eager",
+                   "semantics": "cpu_eager (passed explicitly through the C ABI: the parity gate's oracle is the CPU restatement; the step's tensors are nowhere near the rows where the two scalar policies differ)",
                    "backward": "mask (forward records row bounds + 1-bit STE mask; backward does not re-read x); BOTH gradients are written "
                                "to fresh tensors (the reference's grad_output.clone()); value_product_default = the same step with the "
                                "weight's gradient masked in place (gx == g: rows that cannot clip -- all of a weight's -- are not touched)",

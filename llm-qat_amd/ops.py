@@ -12,13 +12,18 @@ from . import _lib
 
 _DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16, torch.float64: _lib.DTYPE_F64}
 _SEM_NAMES = {"cpu_eager": _lib.SEM_CPU_EAGER, "device_eager": _lib.SEM_DEVICE_EAGER}
-_semantics = _SEM_NAMES[os.environ.get("LLMQAT_AMD_SEMANTICS", "cpu_eager")]
+# Default since round 5: a CUDA tensor gets what the reference computes ON A GPU ("device_eager": ATen's GPU kernels keep an added Python
+# scalar in fp32 and turn `.div(python scalar)` into a multiply by the fp32 reciprocal) -- the drop-in runs on the GPU, so that is the
+# arithmetic it replaces; pinned to the reference's own code by tests/golden/device_scalars.npz and to live ATen on the MI355X
+# (tests/test_gpu_device_scalars.py).  "cpu_eager" (the reference run on CPU tensors, the arithmetic of the round-1 fixtures) stays a switch;
+# CPU tensors served through allow_cpu_tensors() run ATen's own CPU kernels and are not affected by either.
+_semantics = _SEM_NAMES[os.environ.get("LLMQAT_AMD_SEMANTICS", "device_eager")]
 
 
 def set_semantics(name):
-    """'cpu_eager' (default; bit-equal to the reference run on CPU, pinned by fixtures) or
-    'device_eager' (bit-equal to the reference's eager ops run on the GPU).  They differ only for
-    bf16/fp16 rows whose |max| is below ~4e-5 and for fp32 AsymQuantizer (DESIGN.md "Numerics")."""
+    """'device_eager' (default: bit-equal to the reference's eager ops run on a GPU, outside autocast) or 'cpu_eager' (bit-equal to the
+    reference run on CPU).  They differ only for bf16 rows whose |max| is below ~3e-4, fp16 rows with |max| in [2^-13, 2^-12) and for
+    fp32 AsymQuantizer (DESIGN.md "Numerics"); under autocast the arithmetic is the device's either way."""
     global _semantics
     _semantics = _SEM_NAMES[name]
 
@@ -365,6 +370,24 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
             return None
         _lib.check(rc, "quantize_pair")
     return wq, xq, side_w, side_x, rows_w, rows_x, cols
+
+
+def weight_forward(w, w_bits, lo, hi, need):
+    """A QuantizeLinear's weight ALONE (its input was fake-quantized by a sibling projection), shaped like its half of pair_forward:
+    -> (wq, side or None, rows, cols), or None where the pair would not be served either (the caller then takes the ordinary node).
+    Under autocast: the reference's arithmetic rounded once to the operand dtype (the narrow form), as in the pair launch."""
+    if not (w.is_cuda and w.is_contiguous() and w.dim() == 2 and w.numel()):
+        return None
+    if autocast_active(w):
+        if not autocast_narrow_ok(w):
+            return None
+        y, side, rows, cols, got = sym_forward_autocast(w, w_bits, False, wide=False, lo=lo, hi=hi, train="mask" if need else None)
+        if need and got != "mask":
+            return None
+        return y, (side if need else None), rows, cols
+    if need:
+        return train_forward("sym", w, w_bits, False, lo, hi)
+    return sym_quantize(w, w_bits), None, w.shape[0], w.shape[1]
 
 
 def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, inplace_w=False):

@@ -76,7 +76,12 @@ def stats(reset=False):
       wcache_fill / wcache_hit           weight-quant cache (opt-in)
       inplace_taken / inplace_refused:<reason>
                                          weight gradients masked where they stand vs copied, by the guard's reason
-                                         (uncalibrated, storage, anomaly, py_refs, cxx_refs, storage_refs, base_refs)"""
+                                         (uncalibrated, no_refcount_api, storage, anomaly, py_refs, cxx_refs, storage_refs, base_refs)
+      share_disabled:no_region_api / kv_pair_disabled:no_region_api / kv_pair_disabled:no_functorch_api
+                                         calls that ran the reference's launch structure because a private torch API the stateful logic
+                                         leans on is missing in this build (fail closed; warned once)
+      w12_fused_unverified               1-/2-bit weights that took ATen's own abs + mean because the one-launch kernel's restatement of
+                                         ATen's summation order did not verify on this device / torch build"""
     out = dict(_stats)
     if reset:
         _stats.clear()
@@ -111,79 +116,80 @@ def _graph_aware(backward):
 # moments).  With None all the way, a dead branch stays dead (tests/test_gpu_random_programs.py found this).
 
 
-class _FakeQuantFunction(torch.autograd.Function):
-    @staticmethod
-    def _fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow):
-        """The reference under torch.autocast("cuda"): fp32 arithmetic behind the reciprocal, fp32 result (or, for
-        QuantizeLinear's own operands, that result rounded once -- exactly what F.linear's autocast cast does next)."""
+class _Raw:
+    """What one fake-quant forward produced, apart from any autograd node: the result as plain data plus everything a backward needs.
+    `_FakeQuantFunction` makes one and attaches it to its own node; a shared activation (point 1 below) is one `_Raw` that every sibling
+    projection wraps in a node of its OWN (`_SharedAct`), so that no two callers ever share a piece of graph."""
+    __slots__ = ("out", "mode", "saved", "clip", "rows_cols", "grad_dtype")
+
+    def __init__(self, out, mode, saved=(), clip=None, rows_cols=None, grad_dtype=None):
+        self.out, self.mode, self.saved, self.clip, self.rows_cols, self.grad_dtype = out, mode, saved, clip, rows_cols, grad_dtype
+
+
+def _compute(kind, input, clip_val, num_bits, layerwise, narrow, need_grad):
+    """One fake-quant forward -> _Raw.  mode: "cpu" | "none" (no backward will run) | "mask" | "mask_wide" | "bounds" | "plain"."""
+    if input.device.type == "cpu":   # opt-in, plain torch ops (cpu_tensors.py): never a fallback for a CUDA tensor
+        if not cpu_tensors.ENABLED:
+            cpu_tensors.refuse(input, f"{kind}_quantize")
+        return _Raw(cpu_tensors.forward(kind, input, num_bits, layerwise), "cpu", (input, clip_val))   # reference :45 / :104
+    ac = kind == "sym" and ops.autocast_active(input)
+    if not need_grad:  # no backward will run (eval, frozen input): nothing to record or save
+        if ac:
+            return _Raw(ops.sym_forward_autocast(input, num_bits, layerwise, wide=not (narrow and ops.autocast_narrow_ok(input)))[0], "none")
+        return _Raw(ops.sym_quantize(input, num_bits, layerwise) if kind == "sym" else ops.asym_quantize(input, num_bits, layerwise), "none")
+    if ac:
+        # The reference under torch.autocast("cuda"): fp32 arithmetic behind the reciprocal, fp32 result (or, for QuantizeLinear's own
+        # operands, that result rounded once -- exactly what F.linear's autocast cast does next).  The engine casts the reference's fp32
+        # gradient to the input dtype: grad_dtype does it up front.
         mode = _BACKWARD_MODE
         lo, hi = _clip_pair(clip_val)
         narrow = narrow and ops.autocast_narrow_ok(input)
         out, side, rows, cols, got = ops.sym_forward_autocast(input, num_bits, layerwise, wide=not narrow, lo=lo, hi=hi,
                                                               train=None if mode == "plain" else mode)
-        ctx.grad_dtype = input.dtype  # the engine casts the reference's fp32 gradient to the input dtype; do it up front
-        ctx.clip, ctx.rows_cols = (lo, hi), (rows, cols)
-        if got == "mask":
-            ctx.fq_mode = "mask" if narrow else "mask_wide"  # a fp32 result's mask has its own layout
-            ctx.save_for_backward(side)  # bounds + mask (6 % of the tensor) as a SAVED tensor: hooks / checkpointing see it
-            return out
+        if got == "mask":   # bounds + mask (6 % of the tensor) as a SAVED tensor: hooks / checkpointing see it; a fp32 result's mask has its own layout
+            return _Raw(out, "mask" if narrow else "mask_wide", (side,), (lo, hi), (rows, cols), input.dtype)
         if got == "bounds":
-            ctx.fq_mode = "bounds"
-            ctx.save_for_backward(input, clip_val, side)
-        else:
-            ctx.fq_mode = "plain"
-            ctx.save_for_backward(input, clip_val)
-        return out
+            return _Raw(out, "bounds", (input, clip_val, side), (lo, hi), (rows, cols), input.dtype)
+        return _Raw(out, "plain", (input, clip_val), (lo, hi), (rows, cols), input.dtype)
+    mode = "plain" if input.dtype == torch.float64 else _BACKWARD_MODE   # float64: the reference's data flow (saved input)
+    if mode == "mask":
+        lo, hi = _clip_pair(clip_val)
+        res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
+        if res is not None:
+            out, side, rows, cols = res
+            # The side buffer (row bounds + STE bit mask) is a SAVED tensor, not a ctx attribute: saved-tensor hooks (save_on_cpu,
+            # non-reentrant checkpointing's discard) see it and can drop / offload it like any other activation.  The input itself is
+            # not needed again and is not saved.
+            return _Raw(out, "mask", (side,), (lo, hi), (rows, cols))
+        mode = "bounds"
+    fn = ops.sym_quantize if kind == "sym" else ops.asym_quantize
+    if mode == "bounds":
+        out, row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
+        return _Raw(out, "bounds", (input, clip_val, row_bounds), None, ops.rows_cols(tuple(input.shape), layerwise))
+    return _Raw(fn(input, num_bits, layerwise), "plain", (input, clip_val))  # reference :45 / :104 -- the unclipped input itself
 
+
+def _attach(ctx, raw, inplace_grad=False):
+    ctx.fq_mode, ctx.clip, ctx.rows_cols, ctx.grad_dtype = raw.mode, raw.clip, raw.rows_cols, raw.grad_dtype
+    ctx.fq_inplace = inplace_grad  # a QuantizeLinear's own weight: its gradient may be masked where it stands (point 6 below)
+    ctx.fq_st = _state().ref       # whose forward pass this node belongs to (_backward_started)
+    ctx.set_materialize_grads(False)     # a gradient that never arrives stays None (see _no_gradient)
+    if raw.saved:
+        ctx.save_for_backward(*raw.saved)
+
+
+class _FakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def _fwd(kind, ctx, input, clip_val, num_bits, layerwise, narrow=False, inplace_grad=False):
-        ctx.fq_inplace = inplace_grad  # a QuantizeLinear's own weight: its gradient may be masked where it stands (point 6 below)
         if type(num_bits) is not int:
             num_bits = ops.bits_arg(num_bits)   # 8.0 -> 8; 7.5 or a tensor: refused (ops.bits_arg says why)
         if torch.compiler.is_compiling():  # Dynamo traces forward/backward of the Function: same kernels as custom ops (compiled.py)
             ctx.save_for_backward(input, clip_val)
             ctx.fq_mode = "compiled"
             return compiled.fake_quant(kind, input, clip_val, num_bits, layerwise, narrow)
-        ctx.grad_dtype = None
-        ctx.fq_tid = threading.get_ident()   # whose forward pass this node belongs to (_backward_started)
-        ctx.set_materialize_grads(False)     # a gradient that never arrives stays None (see _no_gradient)
-        if input.device.type == "cpu":   # opt-in, plain torch ops (cpu_tensors.py): never a fallback for a CUDA tensor
-            if not cpu_tensors.ENABLED:
-                cpu_tensors.refuse(input, f"{kind}_quantize")
-            ctx.fq_mode = "cpu"
-            ctx.save_for_backward(input, clip_val)   # reference :45 / :104
-            return cpu_tensors.forward(kind, input, num_bits, layerwise)
-        if not ctx.needs_input_grad[0]:  # no backward will run (eval, frozen input): nothing to record or save
-            ctx.fq_mode = "none"
-            if kind == "sym" and ops.autocast_active(input):
-                return ops.sym_forward_autocast(input, num_bits, layerwise, wide=not (narrow and ops.autocast_narrow_ok(input)))[0]
-            return ops.sym_quantize(input, num_bits, layerwise) if kind == "sym" else ops.asym_quantize(input, num_bits, layerwise)
-        if kind == "sym" and ops.autocast_active(input):
-            return _FakeQuantFunction._fwd_autocast(ctx, input, clip_val, num_bits, layerwise, narrow)
-        mode = "plain" if input.dtype == torch.float64 else _BACKWARD_MODE   # float64: the reference's data flow (saved input)
-        ctx.fq_mode = "plain"
-        if mode == "mask":
-            lo, hi = _clip_pair(clip_val)
-            res = ops.train_forward(kind, input, num_bits, layerwise, lo, hi)
-            if res is not None:
-                out, side, rows, cols = res
-                ctx.fq_mode, ctx.clip, ctx.rows_cols = "mask", (lo, hi), (rows, cols)
-                # The side buffer (row bounds + STE bit mask) is a SAVED tensor, not a ctx attribute: saved-tensor hooks
-                # (save_on_cpu, non-reentrant checkpointing's discard) see it and can drop / offload it like any other
-                # activation.  The input itself is not needed again and is not saved.
-                ctx.save_for_backward(side)
-                return out
-            mode = "bounds"
-        fn = ops.sym_quantize if kind == "sym" else ops.asym_quantize
-        if mode == "bounds":
-            out, row_bounds = fn(input, num_bits, layerwise, want_bounds=True)
-            ctx.fq_mode = "bounds"
-            ctx.rows_cols = ops.rows_cols(tuple(input.shape), layerwise)
-            ctx.save_for_backward(input, clip_val, row_bounds)
-        else:
-            out = fn(input, num_bits, layerwise)
-            ctx.save_for_backward(input, clip_val)  # reference :45 / :104 -- the unclipped input itself
-        return out
+        raw = _compute(kind, input, clip_val, num_bits, layerwise, narrow, ctx.needs_input_grad[0])
+        _attach(ctx, raw, inplace_grad)
+        return raw.out
 
     @staticmethod
     @_graph_aware
@@ -194,10 +200,11 @@ class _FakeQuantFunction(torch.autograd.Function):
         if ctx.fq_mode == "none" or grad_output is None:   # nothing to mask: the input needs no gradient (the engine is here for a clip_val
             return None, None, None, None                  # that requires grad, which gets None, :87), or no gradient arrived (_no_gradient)
         if ctx.fq_mode == "cpu":
+            _backward_started(ctx.fq_st)
             input, clip_val = ctx.saved_tensors
             return cpu_tensors.backward(grad_output, input, clip_val), None, None, None
         inplace = ctx.fq_inplace and _INPLACE_WGRAD and _inplace_ok(grad_output)  # (before anything else takes a reference)
-        _backward_started(ctx.fq_tid)
+        _backward_started(ctx.fq_st)
         if ctx.fq_mode == "mask_wide":  # fp32 gradient of the fp32 result -> masked gradient in the input dtype, one pass
             lo, hi = ctx.clip
             rows, cols = ctx.rows_cols
@@ -217,8 +224,7 @@ class _FakeQuantFunction(torch.autograd.Function):
         bounds = saved[2] if len(saved) > 2 else None
         if bounds is not None and not (input.is_contiguous() and grad_output.is_contiguous()):
             bounds = None
-        grad_input = ops.ste_backward(grad_output, input, lo, hi, row_bounds=bounds,
-                                      rows_cols_hint=getattr(ctx, "rows_cols", None))
+        grad_input = ops.ste_backward(grad_output, input, lo, hi, row_bounds=bounds, rows_cols_hint=ctx.rows_cols)
         return grad_input, None, None, None
 
 
@@ -232,7 +238,7 @@ class SymQuantizer(_FakeQuantFunction):
     @classmethod
     def apply(cls, input, clip_val, num_bits, layerwise):
         # the unchanged KV-cache hooks (two consecutive apply calls on k_proj's and v_proj's outputs): one launch, see point 7
-        if _PAIR_KV and cls is SymQuantizer and not layerwise and type(num_bits) is int and not torch._C._are_functorch_transforms_active():
+        if _PAIR_KV and cls is SymQuantizer and not layerwise and type(num_bits) is int:
             out = _kv_hook(input, clip_val, num_bits)
             if out is not None:
                 return out
@@ -324,6 +330,36 @@ def fuse_low_bit_mean(flag=True):
     _W12_FUSED = bool(flag)
 
 
+# The one-launch kernel is bit-identical to the reference only as long as its restatement of ATen's reduction tree (torch's Reduce.cuh:
+# block shape, vectorisation, shuffle order, the num_mp-dependent output split) IS what this torch build does on this device -- a
+# CPX-partitioned MI355X (32 CUs) or another torch version may configure the reduction differently.  So it verifies itself: the first
+# 1-/2-bit weight of each (device, dtype) runs a probe covering both row configurations (a wave per row: cols <= 8128; eight waves per
+# row above) against live `abs().mean(dim=1)`; any differing scale switches the fused path off for that (device, dtype) -- ATen's own
+# reductions then run in front of fq_w12_fwd, three launches, still bit-identical -- and stats() counts `w12_fused_unverified`.
+_w12_verdict = {}
+
+
+def _w12_fused_verified(w):
+    key = (w.device.index, w.dtype)
+    ok = _w12_verdict.get(key)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False      # a probe needs a host read-back: not during graph capture (the three-launch path is capturable)
+        ok = True
+        with torch.no_grad():
+            g = torch.Generator(device=w.device).manual_seed(1234)
+            for rows, cols in ((16, 512), (9, 8128), (8, 8132), (8, 11008)):
+                p = (torch.randn(rows, cols, generator=g, device=w.device) * 0.02).to(w.dtype)
+                res = ops.low_bit_weight_fused(p, 1)
+                if res is not None and not torch.equal(res[1], p.abs().mean(dim=1)):
+                    ok = False
+                    break
+        _w12_verdict[key] = ok
+    if not ok:
+        _count("w12_fused_unverified")
+    return ok
+
+
 # 6. A weight's rows practically never reach the STE clip, so its backward is the identity -- and the reference's
 #    `grad_output.clone()` (:84) exists only to be mutated by the two masked writes (:85-86).  For the WEIGHT operand of a
 #    QuantizeLinear the gradient that arrives is F.linear's freshly computed wgrad (the quantized weight has exactly one
@@ -409,6 +445,8 @@ def _inplace_ok(g):
     base = _ref_base.get("named")
     if base is None:
         return _refuse("uncalibrated")
+    if _storage_use_count is None or not hasattr(g, "_use_count"):   # the private counters the guard reads: without them, never in place
+        return _refuse("no_refcount_api")
     if sys.getrefcount(g) > base[0]:
         return _refuse("py_refs")
     if g._use_count() > base[1]:
@@ -437,28 +475,32 @@ _CLIP = torch.tensor([-2.0, 2.0])  # the literal the reference rebuilds on every
 #
 # 1. q_proj / k_proj / v_proj (modeling_llama_quant.py:313,317,318) and gate_proj / up_proj (:235)
 #    fake-quantize the SAME activation tensor with the same bits.  `_shared_activation` remembers the
-#    last (input -> output) pair per thread and hands the same output (and autograd node) to the
-#    sibling projections.  Gradients are unchanged bit for bit: the STE mask is applied once to the
-#    summed gradient instead of to each summand, and zeroing commutes with the elementwise sum -- as long as
-#    the sharing siblings are the LAST consumers of that input to be created (q/k/v, gate/up: every call
-#    site of the reference model).  If yet another consumer of the same tensor is created after them
-#    (a differently configured quantizer, any other op), the input's gradient is the same sum accumulated
-#    in a different association order: (others + (g_a + g_b)) instead of ((others + g_a) + g_b) -- last-bit
-#    differences in 16-bit dtypes, none in exact arithmetic (tests/test_gpu_share_sequences.py).
-#    A hit requires the very same tensor object at the same version and that no fake-quant backward has run
-#    since (so an output whose graph was already consumed is never handed out again); the remembered outputs are
-#    released when the next backward starts, or replaced by the next module that quantizes an activation the same way.
+#    last fake-quantized activation per thread AS PLAIN DATA (a `_Raw`: the values + the side buffer a
+#    backward needs) and hands it to the sibling projections: the kernel runs once, and since round 5
+#    EVERY SIBLING GETS AN AUTOGRAD NODE OF ITS OWN over it (`_SharedAct`, or the module's `_PairNode`
+#    together with its weight) -- forward launches nothing, backward is that sibling's own STE launch.
+#    That is the reference's graph exactly (one node per module, :246): the input's gradient is the sum
+#    of the siblings' MASKED gradients in the engine's own order, bit for bit in every program, each
+#    sibling's graph can be run and freed on its own (`a.sum().backward(); b.sum().backward()`), and
+#    nothing is shared but read-only data.  (Rounds 1-4 handed the siblings one node: one backward launch
+#    less per group, but a second backward over it raised, and a consumer of the same input created AFTER
+#    the siblings saw that input's gradient summed in another association order -- ADVICE / VERDICT r04.)
+#    A hit requires the very same tensor object at the same version and address, the same grad mode /
+#    autocast state / backward mode / stream / saved-tensor-hooks region; what is remembered is let go of
+#    when the next backward starts, or replaced by the next module that quantizes an activation the same way.
+#    Limit, stated: a write THROUGH `x.data` (or `x.set_`-ing the same storage back) bumps no version counter
+#    and moves no address, so a sibling called after it is served the activation as quantized before the
+#    write -- the reference model never does this; `conservative(True)` / `share_activation_quant(False)`
+#    is the switch (tests/test_gpu_share_sequences.py::test_write_through_data_is_a_stated_limit).
 # 2. Under activation checkpointing every weight is fake-quantized twice per step (first forward, then
 #    the recompute -- reentrant or not) although it has not changed.  With the weight cache on (opt-in:
 #    it keeps one quantized copy per layer alive from the first use until the second), the second use
 #    within a step reuses the first result.  The key holds the parameter's identity, version counter and
 #    storage address, so an optimizer step / load_state_dict / .data swap can never be served stale.
 # ---------------------------------------------------------------------------------------------
-_bwd_epoch = {}   # forward thread id -> how many fake-quant backward passes have started on graphs that thread built
 _SHARE_ACT = os.environ.get("LLMQAT_AMD_SHARE_ACT", "1") != "0"
 _WEIGHT_CACHE = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") in ("1", "persistent")
 _WEIGHT_CACHE_PERSISTENT = os.environ.get("LLMQAT_AMD_WEIGHT_CACHE", "0") == "persistent"
-_tls = threading.local()
 
 
 def share_activation_quant(flag=True):
@@ -478,30 +520,66 @@ def enable_weight_quant_cache(flag=True, persistent=False):
 _MODE_CODE = {"mask": 0, "bounds": 1, "plain": 2}
 
 
-def _state_word(x):
-    """everything ambient that decides which arithmetic / data flow a call takes, folded into one int (part of the cache keys)"""
-    return (_MODE_CODE[_BACKWARD_MODE] + 4 * ops._semantics + (8 if torch.is_grad_enabled() else 0)
-            + (16 if ops.autocast_active(x) else 0))
+class _ThreadState:
+    """Everything the host logic remembers between calls, per FORWARD thread (thread-local: it dies with its thread, so a short-lived
+    evaluation or DataParallel replica thread leaves nothing behind).  A backward runs on the autograd engine's threads: its nodes carry
+    a weak reference to the state of the thread whose forward built them (`ctx.fq_st`), which is how `_backward_started` reaches it."""
+    __slots__ = ("acts", "outs", "kv", "epoch", "ref", "__weakref__")
+
+    def __init__(self):
+        self.acts = {}        # key -> (weakref(input), its version, its address, _Raw, the result's version, needs grad, region, stream)
+        self.outs = []        # the last few QuantizeLinear outputs of this thread, in order (weakly): what the KV hooks pair
+        self.kv = None        # the pending half of a K + V launch
+        self.epoch = 0        # fake-quant backward passes started on graphs this thread built
+        self.ref = weakref.ref(self)
 
 
-def _act_key(quantizer, x, num_bits, layerwise):
-    return (quantizer, num_bits, layerwise, _state_word(x))
+_tls = threading.local()
 
 
-def _backward_started(tid):
-    """every fake-quant backward calls this first, with the id of the thread whose forward built its node: what THAT thread remembered
-    before (shared activations, a pending V of the K/V hooks) is never handed out afterwards -- those graphs may already be consumed --
-    and is let go of now, graphs included.  Per forward thread, not global: the backward itself runs on the autograd engine's threads,
-    and another thread's forward pass (a DataParallel replica, an evaluation thread) keeps what it remembered."""
-    _bwd_epoch[tid] = _bwd_epoch.get(tid, 0) + 1
-    if tid in _act_caches:
-        del _act_caches[tid]
-    if tid in _kv_stash:
-        _kv_discard(tid)
+def _state():
+    st = getattr(_tls, "st", None)
+    if st is None:
+        st = _tls.st = _ThreadState()
+    return st
 
 
-_act_caches = {}   # forward thread id -> {key: (weakref(input), its version, output, its version, backward epoch, input.requires_grad, region)}
+def _backward_started(ref):
+    """every fake-quant backward calls this first, with the (weak) state of the thread whose forward built its node: what THAT thread
+    remembered before (shared activations, a pending V of the K/V hooks) is let go of now -- side buffers included -- and a K/V guess made
+    before this point is never honoured afterwards.  Per forward thread, not global: another thread's forward pass (a DataParallel
+    replica, an evaluation thread) keeps what it remembered."""
+    st = ref()
+    if st is None:      # the forward thread is gone
+        return
+    st.epoch += 1
+    if st.acts:
+        st.acts = {}    # (rebinding, not clearing: the forward thread may be reading the old dict)
+    if st.kv is not None:
+        _kv_discard(st)
+
+
+# The saved-tensor-hooks region API is private (torch._C._autograd._top_saved_tensors_default_hooks).  Without it the host logic cannot
+# tell a checkpointed region from its surroundings, and remembering anything across calls could hand a non-reentrant checkpoint's first
+# pass something its recompute cannot repeat (CheckpointError): so WITHOUT IT NOTHING IS REMEMBERED -- activation sharing and the K/V
+# pairing switch themselves off (fail closed), stats() counts `share_disabled:no_region_api`, and a warning says so once.
 _top_hooks = getattr(torch._C._autograd, "_top_saved_tensors_default_hooks", None)
+_functorch_active = getattr(torch._C, "_are_functorch_transforms_active", None)
+_warned = set()
+
+
+def _disabled(what, why):
+    _count(f"{what}_disabled:{why}")
+    if (what, why) not in _warned:
+        _warned.add((what, why))
+        _log.warning("llm_qat_amd: %s is switched off: %s is not available in this torch build (same results, the reference's launch structure; "
+                     "stats() counts it under %s_disabled:%s)", what, why, what, why)
+    return False
+
+
+def _memory_ok(what):
+    """may the host logic remember something across calls?  (fail closed on a missing private API)"""
+    return True if _top_hooks is not None else _disabled(what, "no_region_api")
 
 
 def _region():
@@ -509,58 +587,83 @@ def _region():
     activation checkpointing is such a context -- one for the first pass, another for the recompute -- and requires both passes to save
     the same tensors: something remembered OUTSIDE a checkpointed region must not be used INSIDE it (the recompute, which starts from an
     empty memory, could not repeat that), so what is remembered is only handed out within the region it was made in.  A checkpoint
-    around a whole decoder layer -- the reference's, modeling_llama_quant.py:732-747 -- contains all siblings and loses nothing."""
-    if _top_hooks is None:
-        return None
+    around a whole decoder layer -- the reference's, modeling_llama_quant.py:732-747 -- contains all siblings and loses nothing.
+    Callers have checked `_memory_ok()` first."""
     h = _top_hooks(True)
     return None if h is None else h[0]
 
 
-def _act_lookup(key, x):
-    tid = threading.get_ident()
-    cache = _act_caches.get(tid)
-    ent = cache.get(key) if cache else None
+def _state_word(x):
+    """everything ambient that decides which arithmetic / data flow a call takes, folded into one int (part of the cache keys)"""
+    return (_MODE_CODE[_BACKWARD_MODE] + 4 * ops._semantics + (8 if torch.is_grad_enabled() else 0)
+            + (16 if ops.autocast_active(x) else 0))
+
+
+def _act_lookup(st, key, x, region, stream):
+    ent = st.acts.get(key)
     if ent is not None:
-        rin, ver_in, y, ver_out, epoch, needs_grad, region = ent
-        # (requires_grad can be switched on a leaf between two sibling calls without touching its version counter: an output built
-        # without a graph must not be handed to a call that needs one, nor the reverse)
-        if (rin() is x and ver_in == x._version and ver_out == y._version and epoch == _bwd_epoch.get(tid, 0) and needs_grad == x.requires_grad
-                and region is _region()):
-            return y
+        rin, ver_in, addr, raw, ver_out, needs_grad, reg, strm = ent
+        # (requires_grad can be switched on a leaf between two sibling calls without touching its version counter: a result recorded
+        # without side buffers must not be handed to a call that needs a backward, nor the reverse)
+        if (rin() is x and ver_in == x._version and addr == x.data_ptr() and ver_out == raw.out._version and needs_grad == x.requires_grad
+                and reg is region and strm == stream):
+            return raw
     return None
 
 
-def _act_store(key, x, y):
+def _act_store(st, key, x, raw, region, stream):
     """One entry per key: the next module that quantizes an activation with the same settings -- the next layer's q_proj / gate_proj --
     replaces it, and the first fake-quant backward that starts drops them all (`_backward_started`), so at most one fake-quantized
     activation per key outlives its siblings, and none outlives the forward pass.  A dead input can never match (`rin() is x` on a
     dead weak reference is False), so id reuse is harmless."""
-    tid = threading.get_ident()
-    cache = _act_caches.get(tid)
-    if cache is None:
-        cache = _act_caches[tid] = {}
-    cache[key] = (weakref.ref(x), x._version, y, y._version, _bwd_epoch.get(tid, 0), x.requires_grad, _region())
+    st.acts[key] = (weakref.ref(x), x._version, x.data_ptr(), raw, raw.out._version, x.requires_grad, region, stream)
+
+
+class _SharedAct(torch.autograd.Function):
+    """One sibling's OWN autograd node over an activation some launch has already fake-quantized (a `_Raw`): forward launches nothing,
+    backward is the ordinary STE backward of `_FakeQuantFunction` over the raw's side buffer."""
+
+    @staticmethod
+    def forward(ctx, x, raw):
+        _attach(ctx, raw)
+        return raw.out.view_as(raw.out)   # a tensor of this node's own: the raw stays plain data for the next sibling
+
+    backward = _FakeQuantFunction.backward
+
+
+def _wrap_shared(x, raw):
+    if raw.mode == "none" or not (torch.is_grad_enabled() and x.requires_grad):
+        return raw.out
+    out = _SharedAct.apply(x, raw)
+    return out
 
 
 def _shared_activation(quantizer, x, num_bits, layerwise):
     if quantizer is SymQuantizer:
         quantizer = _SymQuantizerOperand
-    if not _SHARE_ACT or x.is_inference():   # (inference tensors have no version counter: nothing is remembered about them)
-        return quantizer.apply(x, _CLIP, num_bits, layerwise)
-    key = _act_key(quantizer, x, num_bits, layerwise)
-    y = _act_lookup(key, x)
-    if y is None:
+    if not _SHARE_ACT or x.is_inference() or torch.compiler.is_compiling() or not _memory_ok("share"):
+        return quantizer.apply(x, _CLIP, num_bits, layerwise)   # (inference tensors have no version counter: nothing is remembered about them)
+    st = _state()
+    key = (quantizer, num_bits, layerwise, _state_word(x))
+    region, stream = _region(), (ops._stream(x) if x.is_cuda else 0)
+    raw = _act_lookup(st, key, x, region, stream)
+    if raw is None:
         _count("act_share_miss")
-        y = quantizer.apply(x, _CLIP, num_bits, layerwise)
-        _act_store(key, x, y)
+        if type(num_bits) is not int:
+            num_bits = ops.bits_arg(num_bits)
+        raw = _compute("asym" if quantizer is AsymQuantizer else "sym", x, _CLIP, num_bits, layerwise, quantizer is _SymQuantizerOperand,
+                       torch.is_grad_enabled() and x.requires_grad)
+        _act_store(st, key, x, raw, region, stream)
     else:
         _count("act_share_hit")
-    return y
+    return _wrap_shared(x, raw)
 
 
 # 3. QuantizeLinear needs its weight [out, in] and its input [tokens, in] fake-quantized at the same moment, and both
 #    reduce over `in` (same row length = same launch shape): one two-tensor launch forward, one backward (F.linear's
 #    backward produces both gradients together), instead of two each -- a launch carries ~2.8 us of fixed cost.
+#    A sibling that finds its input already fake-quantized launches its weight alone and still takes ONE backward launch for
+#    both of its gradients (its own `_PairNode` over its weight's result and the shared activation data).
 _PAIR = os.environ.get("LLMQAT_AMD_PAIR_OPERANDS", "1") != "0"
 
 
@@ -570,17 +673,21 @@ def pair_operands(flag=True):
 
 
 class _PairNode(torch.autograd.Function):
-    """Autograd node over the results of one ops.pair_forward launch: weight and input of a QuantizeLinear, whose two results have one
-    consumer, that module's F.linear, and so live or die together.  (K and V of the KV hooks share a forward launch but never a node.)"""
+    """Autograd node over a QuantizeLinear's two operands: the results of one ops.pair_forward launch, or a weight's own launch + an
+    activation a sibling has already fake-quantized.  The two results have one consumer, that module's F.linear, and so live or die
+    together.  (K and V of the KV hooks share a forward launch but never a node.)"""
 
     @staticmethod
-    def forward(ctx, weight, input, res, clip=(-2.0, 2.0), weight_first=False):
+    def forward(ctx, weight, input, res, clip=(-2.0, 2.0), weight_first=False, shared_x=False):
         wq, xq, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
-        ctx.dtype, ctx.clip, ctx.fq_tid = weight.dtype, clip, threading.get_ident()
+        ctx.dtype, ctx.clip, ctx.fq_st = weight.dtype, clip, _state().ref
         ctx.inplace_w = bool(weight_first)  # tensor 0 is a QuantizeLinear's weight: its gradient may be handed on by reference
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
-        # (wq / xq are fresh tensors of the launch that nothing else refers to: they become this node's outputs as they are)
+        # (wq / xq are fresh tensors of the launch that nothing else refers to: they become this node's outputs as they are -- unless
+        # xq is remembered for the sibling projections: then this node gets a tensor of its own over the same data)
+        if shared_x:
+            xq = xq.view_as(xq)
         # An operand that needs no gradient (frozen weight, input without grad) gets a result that needs none either, as
         # SymQuantizer.apply gives in the reference: F.linear's backward then skips the wgrad / dgrad GEMM it would
         # otherwise run only for this node to throw the result away.
@@ -593,7 +700,7 @@ class _PairNode(torch.autograd.Function):
     @_graph_aware
     def backward(ctx, gw, gx):
         inplace_w = ctx.inplace_w and _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
-        _backward_started(ctx.fq_tid)
+        _backward_started(ctx.fq_st)
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lo, hi = ctx.clip
         side_w, side_x = ctx.saved_tensors
@@ -603,9 +710,9 @@ class _PairNode(torch.autograd.Function):
             gw = None
         gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
         if gw is None and gx is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=inplace_w)
-        return ow, ox, None, None, None
+        return ow, ox, None, None, None, None
 
 
 def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
@@ -643,16 +750,16 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
 #        key_states   = SymQuantizer.apply(key_states,   clip_k, kv_bits, False)
 #        value_states = SymQuantizer.apply(value_states, clip_v, kv_bits, False)
 #    are two launches forward and two backward on tensors of one shape.  With the call site UNTOUCHED: every QuantizeLinear
-#    notes its output (a weak reference, per thread); when SymQuantizer.apply receives such an output and the very next noted
-#    output has the same shape / dtype / device (K, then V), both are fake-quantized in ONE forward launch, K's result is
-#    returned and V's is kept -- as plain data, outside any graph -- for the apply call that follows, which must present that very
-#    tensor, unmodified, with the same clip / bits / grad mode / autocast state and no fake-quant backward in between; anything else
-#    discards it (the speculation then cost one tensor's forward, nothing else).  K and V each get their OWN autograd node over
-#    their own side buffer (two backward launches, as in the reference; the explicit quantize_kv() call does the same): a node over
-#    both would tie V's producer into K's graph -- before anyone asked for V, or although its result ends up unused.
-#    The decision depends only on the call sequence, so a checkpointed forward and its recompute build the same graph.
+#    notes its output (a weak reference, per thread); when SymQuantizer.apply receives such an
+#    output and the very next noted output has the same shape / dtype / device / stream (K, then V), both are fake-quantized in ONE
+#    forward launch, K's result is returned and V's is kept -- as plain data, outside any graph -- for the apply call that follows,
+#    which must present that very tensor, unmodified, with the same clip / bits / grad mode / autocast state / stream and no fake-quant
+#    backward in between; anything else discards it (the speculation then cost one tensor's forward, nothing else).  K and V each get
+#    their OWN autograd node over their own side buffer (two backward launches, as in the reference; the explicit quantize_kv() call
+#    does the same): a node over both would tie V's producer into K's graph -- before anyone asked for V, or although its result ends
+#    up unused.  The decision depends only on the call sequence, so a checkpointed forward and its recompute build the same graph.
 #    Results and gradients are bit-identical to the two calls (tests/test_tiny_llama.py, tests/test_gpu_features.py).
-#    LLMQAT_AMD_PAIR_KV=0 / pair_kv_hooks(False) turn it off.
+#    LLMQAT_AMD_PAIR_KV=0 / pair_kv_hooks(False) turn it off; so does a torch build without the private APIs it leans on (fail closed).
 _PAIR_KV = os.environ.get("LLMQAT_AMD_PAIR_KV", "1") != "0"
 
 
@@ -661,29 +768,26 @@ def pair_kv_hooks(flag=True):
     _PAIR_KV = bool(flag)
 
 
-def _note_output(out):
-    """QuantizeLinear.forward: remember (weakly) the last few outputs of this thread, in order"""
+def _note_output(st, out):
+    """QuantizeLinear.forward: remember (weakly) the last few outputs of this thread, in order, with the stream that produced them"""
     if out.is_inference():   # no version counter (torch.inference_mode): such outputs are never paired
         return
-    rec = getattr(_tls, "outs", None)
-    if rec is None:
-        rec = _tls.outs = []
+    rec = st.outs
     if len(rec) >= 4:
         del rec[0]
-    rec.append((weakref.ref(out), out._version, _region()))
+    rec.append((weakref.ref(out), out._version, _region() if _top_hooks is not None else None, ops._stream(out)))
 
 
-def _kv_state(clip_val, num_bits):
-    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops._semantics, _bwd_epoch.get(threading.get_ident(), 0), _region())
+def _kv_state(st, clip_val, num_bits, stream):
+    return (_clip_pair(clip_val), num_bits, torch.is_grad_enabled(), torch.is_autocast_enabled("cuda"), _BACKWARD_MODE, ops._semantics, st.epoch, _region(), stream)
 
 
 _kv_off = set()   # call signatures whose speculation was thrown away once: they stop pairing (ADVICE r03)
-_kv_stash = {}    # forward thread id -> (weakref(V), version, (V's result, its side buffer, rows, cols, clip), state, signature): the pending half of a K+V launch
 
 
-def _kv_discard(tid):
-    """a V result nobody asked for: forget it (and its graph + side buffers), and stop guessing for that call signature"""
-    stash = _kv_stash.pop(tid, None)
+def _kv_discard(st):
+    """a V result nobody asked for: forget it (and its side buffer), and stop guessing for that call signature"""
+    stash, st.kv = st.kv, None
     if stash is None:
         return
     _count("kv_pair_discarded")
@@ -697,17 +801,23 @@ def _kv_hook(x, clip_val, num_bits):
     if (not (_PAIR and _BACKWARD_MODE == "mask" and x.is_cuda and 1 <= num_bits < 32 and x.dim() <= 3) or x.is_inference()
             or torch.compiler.is_compiling()):
         return None
-    tid = threading.get_ident()
-    stash = _kv_stash.get(tid)
+    if _functorch_active is None:
+        _disabled("kv_pair", "no_functorch_api")
+        return None
+    if _functorch_active() or not _memory_ok("kv_pair"):
+        return None
+    st = _state()
+    stream = ops._stream(x)
+    stash = st.kv
     if stash is not None:
         ref, ver, vres, state, sig = stash
-        if ref() is x and ver == x._version and state == _kv_state(clip_val, num_bits):
-            del _kv_stash[tid]
+        if ref() is x and ver == x._version and state == _kv_state(st, clip_val, num_bits, stream):
+            st.kv = None
             _count("kv_pair_hit")
             vq, side_v, rows_v, cols, clip = vres   # V: quantized together with K a moment ago; its autograd node is built only now
             return vq if side_v is None else _PrecomputedAct.apply(x, vq, side_v, rows_v, cols, clip)
-        _kv_discard(tid)
-    rec = getattr(_tls, "outs", None)
+        _kv_discard(st)
+    rec = st.outs
     if not rec:
         return None
     for i in range(len(rec) - 1):
@@ -717,6 +827,8 @@ def _kv_hook(x, clip_val, num_bits):
             region = _region()
             if rec[i][2] is not region or rec[i + 1][2] is not region:
                 return None     # K's or V's projection ran in another saved-tensor-hooks region (see _region)
+            if rec[i][3] != stream or rec[i + 1][3] != stream:
+                return None     # produced on another stream than the one this launch would read them on: no pairing
             v, vver = rec[i + 1][0](), rec[i + 1][1]
             if (v is None or v is x or vver != v._version or v.shape != x.shape or v.dtype != x.dtype or v.device != x.device
                     or not v.is_contiguous() or not x.is_contiguous() or v.requires_grad != x.requires_grad):
@@ -736,17 +848,17 @@ def _kv_hook(x, clip_val, num_bits):
             # a loss that never uses V (a checkpointed producer would be recomputed and hand ZERO gradients to its parameters where the
             # reference leaves None: tests/test_gpu_random_programs.py).  Each of K and V gets its own node over its own side buffer.
             kq, vq, side_k, side_v, rows_k, rows_v, cols = res
-            _kv_stash[tid] = (weakref.ref(v), v._version, (vq, side_v if need else None, rows_v, cols, (lo, hi)), _kv_state(clip_val, num_bits), sig)
+            st.kv = (weakref.ref(v), v._version, (vq, side_v if need else None, rows_v, cols, (lo, hi)), _kv_state(st, clip_val, num_bits, stream), sig)
             return _PrecomputedAct.apply(x, kq, side_k, rows_k, cols, (lo, hi)) if need else kq
     return None
 
 
 def reset_learned_state():
-    """forget what the host logic has learned about call sites (K/V signatures that stopped pairing) and everything it remembers
-    between calls (a pending V result, the last fake-quantized activations)"""
+    """forget what the host logic has learned about call sites (K/V signatures that stopped pairing) and everything the CALLING thread
+    remembers between calls (a pending V result, the last fake-quantized activations, the outputs it noted)"""
     _kv_off.clear()
-    _kv_stash.clear()
-    _act_caches.clear()
+    st = _state()
+    st.acts, st.kv, st.outs = {}, None, []
 
 
 def conservative(flag=True):
@@ -804,7 +916,7 @@ class _PrecomputedAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, side, rows, cols, clip):
-        ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_tid = (rows, cols), clip, x.dtype, threading.get_ident()
+        ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_st = (rows, cols), clip, x.dtype, _state().ref
         ctx.wide = y.dtype != x.dtype
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side)
@@ -815,7 +927,7 @@ class _PrecomputedAct(torch.autograd.Function):
     def backward(ctx, grad_output):
         if grad_output is None:
             return None, None, None, None, None, None
-        _backward_started(ctx.fq_tid)
+        _backward_started(ctx.fq_st)
         (side,) = ctx.saved_tensors
         lo, hi = ctx.clip
         rows, cols = ctx.rows_cols
@@ -845,7 +957,7 @@ class QuantizeLinear(nn.Linear):
             if not cpu_tensors.ENABLED:
                 cpu_tensors.refuse(w, "low_bit_weight")
             return _LowBitWeightCpu.apply(w, self.w_bits, self.weight_layerwise)
-        if _W12_FUSED and not self.weight_layerwise and w.is_cuda and w.is_contiguous():
+        if _W12_FUSED and not self.weight_layerwise and w.is_cuda and w.is_contiguous() and _w12_fused_verified(w):
             try:
                 return _LowBitWeightFused.apply(w, self.w_bits)
             except _NotServed:
@@ -899,11 +1011,16 @@ class QuantizeLinear(nn.Linear):
         return cached[0]
 
     def _pair_forward(self, input_):
-        """weight and input in one launch; None when the pair is not applicable (then the ordinary two calls run)"""
+        """weight and input of this module under ONE autograd node: both in one launch, or -- when a sibling projection has already
+        fake-quantized this input -- the weight's own launch + the remembered activation.  None when not applicable (then the ordinary
+        two calls run)."""
         if not (_PAIR and _BACKWARD_MODE == "mask" and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
             return None
-        if input_.is_inference() or self.weight.is_inference():
+        weight = self.weight
+        if input_.is_inference() or weight.is_inference():
             return None   # no version counters under torch.inference_mode: nothing is paired, shared or remembered
+        if self.act_quantizer is not SymQuantizer or self.act_layerwise or self.weight_layerwise:
+            return None
         wkey = None
         if _WEIGHT_CACHE:
             # With the weight cache on, the FIRST use of a weight in a step still shares a launch with its input and fills the
@@ -912,40 +1029,52 @@ class QuantizeLinear(nn.Linear):
             ent = getattr(self, "_fq_wcache", None)
             if ent is not None and ent[0] == wkey:
                 return None
-        if self.act_quantizer is not SymQuantizer or self.act_layerwise or self.weight_layerwise:
-            return None
-        key = _act_key(_SymQuantizerOperand, input_, self.a_bits, False) if _SHARE_ACT else None
-        if key is not None:
-            if _act_lookup(key, input_) is not None:
-                return None   # a sibling projection already quantized this activation: only the weight is left to do
         grad = torch.is_grad_enabled()
-        res = ops.pair_forward(self.weight, input_, self.w_bits, self.a_bits, -2.0, 2.0,
-                               (grad and self.weight.requires_grad) or wkey is not None, grad and input_.requires_grad)
+        need_w, need_x = grad and weight.requires_grad, grad and input_.requires_grad
+        share = _SHARE_ACT and _memory_ok("share")
+        if share:
+            st = _state()
+            key = (_SymQuantizerOperand, self.a_bits, False, _state_word(input_))
+            region, stream = _region(), (ops._stream(input_) if input_.is_cuda else 0)
+            raw = _act_lookup(st, key, input_, region, stream)
+            if raw is not None:
+                # a sibling projection already quantized this activation: only the weight is left to do.  One node over both where the
+                # remembered data has the pair's shape (mask mode, operand dtype); otherwise the two ordinary nodes
+                if wkey is not None or raw.mode not in ("mask", "none") or raw.out.dtype != weight.dtype:
+                    return None
+                res = ops.weight_forward(weight, self.w_bits, -2.0, 2.0, need_w)
+                if res is None:
+                    return None
+                _count("act_share_hit")
+                _count("single_launch")
+                wq, side_w, rows_w, cols = res
+                if not (need_w or need_x):
+                    return wq, raw.out
+                rows_x = raw.rows_cols[0] if raw.rows_cols else 0
+                return _PairNode.apply(weight, input_, (wq, raw.out, side_w, raw.saved[0] if need_x else None, rows_w, rows_x, cols), (-2.0, 2.0), True, True)
+        res = ops.pair_forward(weight, input_, self.w_bits, self.a_bits, -2.0, 2.0, need_w or wkey is not None, need_x)
         if res is None:
             return None
+        _count("pair_launch")
+        if share:
+            _count("act_share_miss")
+            rows_x, cols = res[5], res[6]
+            _act_store(st, key, input_, _Raw(res[1], "mask", (res[3],), (-2.0, 2.0), (rows_x, cols)) if need_x else _Raw(res[1], "none"), region, stream)
         if wkey is not None:
             # bounds + mask are recorded even without grad (the recompute pass's backward needs them), and the results are
             # wrapped in the SAME nodes the recompute pass will build (_ReuseQuantizedWeight for the weight, a side-buffer
             # node for the input), so non-reentrant checkpointing sees identical saved tensors in both passes
             rows_w, rows_x, cols = res[4], res[5], res[6]
             side_w, side_x = res[2], res[3]
-            cached = (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:], ops.rows_cols(tuple(self.weight.shape), False))
+            cached = (res[0], side_w[: rows_w * 8].view(torch.float32).view(rows_w, 2), side_w[rows_w * 8:], ops.rows_cols(tuple(weight.shape), False))
             self._fq_wcache = (wkey, cached)
             _count("wcache_fill")
-            _count("pair_launch")
-            wq = _ReuseQuantizedWeight.apply(self.weight, cached, _CLIP) if (grad and self.weight.requires_grad) else res[0]
-            xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if (grad and input_.requires_grad) else res[1]
-            if key is not None:
-                _act_store(key, input_, xq)
+            wq = _ReuseQuantizedWeight.apply(weight, cached, _CLIP) if need_w else res[0]
+            xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if need_x else res[1]
             return wq, xq
-        _count("pair_launch")
-        if grad and (self.weight.requires_grad or input_.requires_grad):
-            wq, xq = _PairNode.apply(self.weight, input_, res, (-2.0, 2.0), True)
-        else:
-            wq, xq = res[0], res[1]
-        if key is not None:
-            _act_store(key, input_, xq)
-        return wq, xq
+        if need_w or need_x:
+            return _PairNode.apply(weight, input_, res, (-2.0, 2.0), True, share)
+        return res[0], res[1]
 
     def export_weight(self, container=None):
         """The integer form of this layer's fake-quantized weight for an inference export: packed bins (int4 for
@@ -974,12 +1103,6 @@ class QuantizeLinear(nn.Linear):
         return out
 
     def forward(self, input_):
-        out = self._forward(input_)
-        if _PAIR_KV and out.is_cuda and not torch.compiler.is_compiling():
-            _note_output(out)   # the KV-cache hooks may follow (point 7)
-        return out
-
-    def _forward(self, input_):
         assert len(self.weight.size()) == 2
         if torch.compiler.is_compiling():
             return self._forward_compiled(input_)
@@ -999,6 +1122,8 @@ class QuantizeLinear(nn.Linear):
         out = nn.functional.linear(input_, weight)
         if self.bias is not None:
             out += self.bias.view(1, -1).expand_as(out)
+        if _PAIR_KV and out.is_cuda:
+            _note_output(_state(), out)   # the KV-cache hooks may follow (point 7): ~1 us of bookkeeping
         return out
 
 

@@ -685,7 +685,7 @@ def test_kv_speculation_stops_after_a_wrong_guess_and_says_so(pkg):
         k_only_step()
     st = pkg.stats()
     assert st.get("kv_pair_launch") == 1 and st.get("kv_pair_discarded") == 1 and st.get("kv_pair_learned_off") == 1 and not st.get("kv_pair_hit"), st
-    assert not U._kv_stash, "the unused V result stayed pinned after the backward"
+    assert U._state().kv is None, "the unused V result stayed pinned after the backward"
     n_first = c.n
     with Counter(pkg.ops, ["pair_forward"]) as c:
         k_only_step()

@@ -141,10 +141,14 @@ def test_quantize_linear_operands_and_results(device_eager):
         QA = E.EagerSym if c["symmetric"] else E.EagerAsym
         ol = F.linear(QA.apply(xl, clip, c["a_bits"], False), E.EagerSym.apply(wl, clip, c["w_bits"], False))
         ol.backward(to_dev(go, dt))
-        assert torch.equal(out, ol) and torch.equal(xd.grad, xl.grad) and torch.equal(lin.weight.grad, wl.grad), c["name"]
+        for a, b in ((out, ol), (xd.grad, xl.grad), (lin.weight.grad, wl.grad)):   # (fp16 rows with a tiny |max| overflow to an infinite scale: NaN == NaN here)
+            assert a.dtype == b.dtype and torch.equal(a.nan_to_num(nan=7.0), b.nan_to_num(nan=7.0)), c["name"]
         ref = torch.from_numpy(G.arr(c, "out").astype(np.float32)) if dt == "fp32" else to_dev(G.arr(c, "out"), dt).float().cpu()
-        tol = (2.0 ** -7 if dt == "bf16" else 2.0 ** -10 if dt == "fp16" else 2.0 ** -20) * ref.abs().max().item() + 1e-30
-        assert (out.float().cpu() - ref).abs().max().item() <= 4 * tol, c["name"]
+        got = out.detach().float().cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), c["name"]
+        fin = torch.isfinite(ref)
+        tol = (2.0 ** -7 if dt == "bf16" else 2.0 ** -10 if dt == "fp16" else 2.0 ** -20) * ref[fin].abs().max().item() + 1e-30
+        assert (got[fin] - ref[fin]).abs().max().item() <= 4 * tol, c["name"]
 
 
 def test_device_eager_is_the_default_for_cuda_tensors():

@@ -516,8 +516,9 @@ def test_paired_operand_launch_is_transparent(pkg, dtype, autocast):
     for a, b in zip(res[True][2], res[False][2]):
         assert torch.equal(a, b)
     assert res[True][2][0][3, 5] == 0
-    # unpaired: 3 weights + 1 shared activation forward, 4 backward = 8 calls; paired: (1 pair + 2 weights) + (1 pair + 2) = 6
-    assert res[False][3] == 8 and res[True][3] == 6, (res[False][3], res[True][3])
+    # unpaired: 3 weights + 1 shared activation forward, 3 weight + 3 activation backwards (round 5: every sibling masks its own input
+    # gradient, as in the reference's graph) = 10 calls; paired: (1 pair + 2 weights) forward + 3 two-tensor backwards = 6
+    assert res[False][3] == 10 and res[True][3] == 6, (res[False][3], res[True][3])
     # eval / no-grad
     with torch.no_grad():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):

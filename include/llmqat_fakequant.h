@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FQ_ABI_VERSION 4 /* 2: + multi-tensor launches, export, row scales, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap;
+#define FQ_ABI_VERSION 5 /* 5: + the *_v entry points: rows that do not follow one another in memory (fq_rows_view);  2: + multi-tensor launches, export, row scales, fq_w12_fwd_rows; 3: the STE mask is a plain row bitmap;
                             4: fq_sym_fwd_autocast takes `sem` (and the autocast modes of pair / multi / export / row_scales honour it),
                                launch status from hipLaunchKernel's return value (the hipGetLastError slot is left alone), fq_qlinear_fwd (an experiment with test hooks in its signature) left the library, fq_w12_fwd_rows sums
                                in ATen's own order (no `sem`) */
@@ -227,6 +227,35 @@ typedef struct { const void* x; void* y; int64_t rows; int bits; float* row_boun
 typedef struct { const void* g; void* gx; int64_t rows; const float* row_bounds; const void* mask; } fq_bwd_tensor;
 int fq_sym_fwd_multi(int n, const fq_fwd_tensor* tensors, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream);
 int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* tensors, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream);
+
+/*
+ * ---- rows that do not follow one another in memory (ABI 5) ------------------------------------------------------------------------
+ * The reference accepts tensors of any strides (models/utils_quant.py:37: ATen handles them) and its elementwise results keep the
+ * input's layout.  The entry points above take contiguous [rows, cols]; the `_v` forms below take, per tensor, an optional
+ * fq_rows_view describing "last dimension contiguous, rows strided" layouts -- a slice / chunk() of the last dimension, the
+ * transpose(0, 1) of a 3-D tensor -- so that the host needs no .contiguous() copy in front of the kernel and no copy back behind it:
+ *     row r of the [rows, cols] view = index (r / n_inner, r % n_inner), starting (r / n_inner) * stride_outer +
+ *     (r % n_inner) * stride_inner ELEMENTS behind the base pointer;  n_inner = 0: contiguous (the view is ignored).
+ * 2-D [R, C] with row stride S: {n_inner = R, stride_outer = 0, stride_inner = S};  3-D [A, B, C] with strides (sa, sb, 1):
+ * {n_inner = B, stride_outer = sa, stride_inner = sb}.  Row bounds and STE masks are indexed by the row number r and are always dense.
+ * Results are bit-identical to the contiguous entry points on the gathered rows.  Rows must fit the single-pass kernels (two-pass /
+ * layerwise shapes: FQ_ERR_UNSUPPORTED); the vector kernels additionally need every row start 16-byte aligned (the forward falls back
+ * to its element-wise kernel otherwise; the mask / x-based backwards answer FQ_ERR_UNSUPPORTED).  rows < 2^31.
+ *   fq_rowwise_fwd_v         SymQuantizer / AsymQuantizer forward (asym = 0 / 1), optionally in training mode (row_bounds_out, + mask_out),
+ *                            no autocast arithmetic
+ *   fq_sym_fwd_multi_v       fq_sym_fwd_multi (n = 1..4, autocast 0 / 1 / 2) with a view per x and per y
+ *   fq_ste_bwd_mask_multi_v  fq_ste_bwd_mask_multi with a view per g and per gx (an in-place tensor: gx == g and equal views)
+ *   fq_ste_bwd_v             the x-re-reading STE backward (fq_ste_bwd / fq_ste_bwd_rows) with views for g, x and gx; row_bounds may be NULL
+ */
+typedef struct { int64_t n_inner; int64_t stride_outer; int64_t stride_inner; } fq_rows_view;
+typedef struct { const void* x; void* y; int64_t rows; int bits; float* row_bounds; void* mask; size_t mask_bytes; fq_rows_view xv, yv; } fq_fwd_tensor_v;
+typedef struct { const void* g; void* gx; int64_t rows; const float* row_bounds; const void* mask; fq_rows_view gv, gxv; } fq_bwd_tensor_v;
+int fq_rowwise_fwd_v(int asym, const void* x, const fq_rows_view* xv, void* y, const fq_rows_view* yv, int64_t rows, int64_t cols, int bits, int dtype,
+                     int sem, float lo, float hi, float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream);
+int fq_sym_fwd_multi_v(int n, const fq_fwd_tensor_v* tensors, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream);
+int fq_ste_bwd_mask_multi_v(int n, const fq_bwd_tensor_v* tensors, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream);
+int fq_ste_bwd_v(const void* g, const fq_rows_view* gv, const void* x, const fq_rows_view* xv, void* gx, const fq_rows_view* gxv, int64_t rows,
+                 int64_t cols, float lo, float hi, const float* row_bounds, int dtype, void* stream);
 
 /*
  * STE backward behind a fp32-result forward (fq_sym_fwd_autocast wide_out = 1 / fq_sym_fwd_pair autocast = 2), the

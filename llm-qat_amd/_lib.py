@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # LLMQAT_AMD_LIB points the loader at another build of the library (A/B runs of kernel variants: tools/ab_bench.sh) -- the product
 # file is never overwritten; fq_build_info() / LIB_PATH say which one is loaded
 LIB_PATH = os.environ.get("LLMQAT_AMD_LIB") or os.path.join(HERE, "libllmqat_fakequant.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
 SEM_CPU_EAGER, SEM_DEVICE_EAGER = 0, 1
@@ -23,6 +23,7 @@ EXPORTS = (
     "fq_ste_mask_bytes", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_ste_bwd_mask",
     "fq_w12_fwd", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_wide",
     "fq_export_bins_bytes", "fq_sym_export", "fq_asym_export", "fq_sym_row_scales", "fq_sym_fwd_multi", "fq_ste_bwd_mask_multi", "fq_w12_fwd_rows",
+    "fq_rowwise_fwd_v", "fq_sym_fwd_multi_v", "fq_ste_bwd_mask_multi_v", "fq_ste_bwd_v",
 )
 MAX_TENSORS = 4  # tensors per multi-tensor launch
 
@@ -34,6 +35,20 @@ class FwdTensor(ctypes.Structure):  # fq_fwd_tensor
 
 class BwdTensor(ctypes.Structure):  # fq_bwd_tensor
     _fields_ = [("g", ctypes.c_void_p), ("gx", ctypes.c_void_p), ("rows", ctypes.c_int64), ("row_bounds", ctypes.c_void_p), ("mask", ctypes.c_void_p)]
+
+
+
+class RowsView(ctypes.Structure):  # fq_rows_view: rows that do not follow one another in memory (strides in elements; n_inner = 0: contiguous)
+    _fields_ = [("n_inner", ctypes.c_int64), ("stride_outer", ctypes.c_int64), ("stride_inner", ctypes.c_int64)]
+
+
+class FwdTensorV(ctypes.Structure):  # fq_fwd_tensor_v
+    _fields_ = FwdTensor._fields_ + [("xv", RowsView), ("yv", RowsView)]
+
+
+class BwdTensorV(ctypes.Structure):  # fq_bwd_tensor_v
+    _fields_ = BwdTensor._fields_ + [("gv", RowsView), ("gxv", RowsView)]
+
 
 BINS_NONE, BINS_INT4, BINS_INT8, BINS_INT16 = 0, 1, 2, 3
 ERR_UNSUPPORTED = -8
@@ -100,6 +115,15 @@ def _bind(L):
     L.fq_sym_fwd_multi.restype = i32
     L.fq_ste_bwd_mask_multi.argtypes = [i32, ctypes.POINTER(BwdTensor), i64, f32, f32, i32, i32, vp]
     L.fq_ste_bwd_mask_multi.restype = i32
+    rv = ctypes.POINTER(RowsView)
+    L.fq_rowwise_fwd_v.argtypes = [i32, vp, rv, vp, rv, i64, i64, i32, i32, i32, f32, f32, vp, vp, sz, vp]
+    L.fq_rowwise_fwd_v.restype = i32
+    L.fq_sym_fwd_multi_v.argtypes = [i32, ctypes.POINTER(FwdTensorV), i64, i32, i32, i32, f32, f32, vp]
+    L.fq_sym_fwd_multi_v.restype = i32
+    L.fq_ste_bwd_mask_multi_v.argtypes = [i32, ctypes.POINTER(BwdTensorV), i64, f32, f32, i32, i32, vp]
+    L.fq_ste_bwd_mask_multi_v.restype = i32
+    L.fq_ste_bwd_v.argtypes = [vp, rv, vp, rv, vp, rv, i64, i64, f32, f32, vp, i32, vp]
+    L.fq_ste_bwd_v.restype = i32
     return L
 
 

@@ -42,9 +42,23 @@ struct MaskArgs {
     float lo = 0.f, hi = 0.f;
 };
 
+// fq_rows_view (elements) -> RowPitch (bytes).  A view that describes contiguous rows stays off.  false: not representable.
+bool set_pitch(RowPitch& p, const fq_rows_view* v, int64_t rows, int64_t cols, int esize) {
+    p = RowPitch{};
+    if (!v || v->n_inner <= 0) return true;
+    if (rows > 0x7FFFFFFF || v->n_inner > 0x7FFFFFFF || v->stride_outer < 0 || v->stride_inner < 0) return false;
+    if (v->stride_inner == cols && (v->n_inner >= rows || v->stride_outer == v->n_inner * cols)) return true;   // contiguous after all
+    p.outer = v->stride_outer * esize;
+    p.inner = v->stride_inner * esize;
+    p.n_inner = (uint32_t)v->n_inner;
+    p.on = 1;
+    return true;
+}
+
 template <bool ASYM>
 int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, int64_t rows, int64_t cols, int bits, int dtype,
-            int sem, void* ws, size_t wsb, void* stream, const MaskArgs* mk = nullptr) {
+            int sem, void* ws, size_t wsb, void* stream, const MaskArgs* mk = nullptr, const fq_rows_view* xv = nullptr,
+            const fq_rows_view* yv = nullptr) {
     if (dtype < 0 || dtype > FQ_DTYPE_F64) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (bits < 1 || bits > 31) return fail(FQ_ERR_BITS, "num_bits=%d outside [1, 31]", bits);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
@@ -54,10 +68,13 @@ int rowwise(const void* x, void* y, int32_t* idx, float* scale, float* bounds, i
     if (x == y) return fail(FQ_ERR_ARG, "in-place (y == x) is not supported");
     if (dtype == FQ_DTYPE_F64) {  // correctness path in double arithmetic; no training-mode side buffers
         if (bounds || mk) return fail(FQ_ERR_DTYPE, "float64 tensors: row bounds / STE mask are not produced (use fq_ste_bwd, the reference's data flow)");
+        if ((xv && xv->n_inner > 0) || (yv && yv->n_inner > 0)) return fail(FQ_ERR_UNSUPPORTED, "float64 tensors: contiguous rows only");
         return launch_f64_rowwise(ASYM, x, y, idx, scale, rows, cols, bits, sem, (hipStream_t)stream);
     }
     const Consts c = make_consts(bits, dtype, sem);
     RowArgs a{x, y, idx, scale, bounds, rows, cols, c.sym, c.asym, nullptr, 0, 0.f, 0.f, 0u, rows, 0, {}};
+    if (!set_pitch(a.xp, xv, rows, cols, esize_of(dtype)) || !set_pitch(a.yp, yv, rows, cols, esize_of(dtype)))
+        return fail(FQ_ERR_SHAPE, "fq_rows_view: negative stride, or more than 2^31 - 1 rows");
     if (mk) {
         if (!mk->mask || !bounds) return fail(FQ_ERR_NULL, "train-mode forward needs row_bounds_out and mask_out");
         const int64_t mrw = mask_row_words(cols, esize_of(dtype));
@@ -168,7 +185,8 @@ FQ_API int fq_sym_fwd_autocast(const void* x, void* y, int64_t rows, int64_t col
                                   : launch_sym_autocast<F16>(wide_out != 0, a, workspace, workspace_bytes, st);
 }
 
-FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+static int sym_fwd_multi_impl(int n, const fq_fwd_tensor* t, const fq_rows_view* const* xv, const fq_rows_view* const* yv, int64_t cols, int dtype,
+                              int sem, int autocast, float lo, float hi, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (n < 1 || n > 1 + MAX_MORE || !t) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
     if (sem != FQ_SEM_CPU_EAGER && sem != FQ_SEM_DEVICE_EAGER) return fail(FQ_ERR_ARG, "unknown semantics code %d", sem);
@@ -191,8 +209,18 @@ FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dty
               host_rb(hi, dtype), ste_clip_key(host_rb(lo, dtype), host_rb(hi, dtype), dtype), t[0].rows, n - 1, {}};
     int64_t begin = t[0].rows;
     for (int i = 1; i < n; ++i) {
-        a.more[i - 1] = TensorSlot{begin, t[i].x, t[i].y, t[i].row_bounds, (uint64_t*)t[i].mask, make_consts(t[i].bits, dtype, sem).sym.qmax};
+        a.more[i - 1] = TensorSlot{begin, t[i].x, t[i].y, t[i].row_bounds, (uint64_t*)t[i].mask, make_consts(t[i].bits, dtype, sem).sym.qmax, {}, {}};
         begin += t[i].rows;
+    }
+    {   // rows that do not follow one another (the _v entry point); the results of an autocast = 2 launch are fp32
+        const int xe = esize_of(dtype), ye = autocast == 2 ? 4 : xe;
+        bool okv = true;
+        for (int i = 0; i < n; ++i) {
+            RowPitch& px = i ? a.more[i - 1].xp : a.xp;
+            RowPitch& py = i ? a.more[i - 1].yp : a.yp;
+            okv = okv && set_pitch(px, xv ? xv[i] : nullptr, t[i].rows, cols, xe) && set_pitch(py, yv ? yv[i] : nullptr, t[i].rows, cols, ye);
+        }
+        if (!okv) return fail(FQ_ERR_SHAPE, "fq_rows_view: negative stride, or more than 2^31 - 1 rows");
     }
     hipStream_t st = (hipStream_t)stream;
     if (autocast) {
@@ -206,6 +234,31 @@ FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dty
     }
 }
 
+FQ_API int fq_sym_fwd_multi(int n, const fq_fwd_tensor* t, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+    return sym_fwd_multi_impl(n, t, nullptr, nullptr, cols, dtype, sem, autocast, lo, hi, stream);
+}
+
+FQ_API int fq_sym_fwd_multi_v(int n, const fq_fwd_tensor_v* tv, int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
+    if (n < 1 || n > 1 + MAX_MORE || !tv) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
+    fq_fwd_tensor t[1 + MAX_MORE];
+    const fq_rows_view *xv[1 + MAX_MORE], *yv[1 + MAX_MORE];
+    for (int i = 0; i < n; ++i) {
+        t[i] = fq_fwd_tensor{tv[i].x, tv[i].y, tv[i].rows, tv[i].bits, tv[i].row_bounds, tv[i].mask, tv[i].mask_bytes};
+        xv[i] = &tv[i].xv;
+        yv[i] = &tv[i].yv;
+    }
+    return sym_fwd_multi_impl(n, t, xv, yv, cols, dtype, sem, autocast, lo, hi, stream);
+}
+
+FQ_API int fq_rowwise_fwd_v(int asym, const void* x, const fq_rows_view* xv, void* y, const fq_rows_view* yv, int64_t rows, int64_t cols, int bits,
+                            int dtype, int sem, float lo, float hi, float* row_bounds_out, void* mask_out, size_t mask_bytes, void* stream) {
+    MaskArgs mk;
+    mk.mask = mask_out; mk.bytes = mask_bytes; mk.lo = lo; mk.hi = hi;
+    const MaskArgs* m = mask_out ? &mk : nullptr;
+    return asym ? rowwise<true>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, m, xv, yv)
+                : rowwise<false>(x, y, nullptr, nullptr, row_bounds_out, rows, cols, bits, dtype, sem, nullptr, 0, stream, m, xv, yv);
+}
+
 FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, float* row_bounds0, void* mask0, size_t mask_bytes0,
                            const void* x1, void* y1, int64_t rows1, int bits1, float* row_bounds1, void* mask1, size_t mask_bytes1,
                            int64_t cols, int dtype, int sem, int autocast, float lo, float hi, void* stream) {
@@ -213,7 +266,8 @@ FQ_API int fq_sym_fwd_pair(const void* x0, void* y0, int64_t rows0, int bits0, f
     return fq_sym_fwd_multi(2, t, cols, dtype, sem, autocast, lo, hi, stream);
 }
 
-FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream) {
+static int ste_bwd_mask_multi_impl(int n, const fq_bwd_tensor* t, const fq_rows_view* const* gv, const fq_rows_view* const* ov, int64_t cols, float lo,
+                                   float hi, int dtype, int wide_grad, void* stream) {
     if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
     if (wide_grad && dtype == FQ_DTYPE_F32) return fail(FQ_ERR_DTYPE, "fp32-gradient STE backward: the input dtype must be bf16 / fp16");
     if (n < 1 || n > 1 + MAX_MORE || !t) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
@@ -229,7 +283,14 @@ FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, fl
     hi = host_rb(hi, dtype);
     SteLaunch L{};
     L.n = n;
-    for (int i = 0; i < n; ++i) L.t[i] = SteSlot{t[i].g, t[i].gx, t[i].row_bounds, (const uint64_t*)t[i].mask, t[i].rows, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        L.t[i] = SteSlot{t[i].g, t[i].gx, t[i].row_bounds, (const uint64_t*)t[i].mask, t[i].rows, 0, 0, {}, {}};
+        const int oe = esize_of(dtype), ge = wide_grad ? 4 : oe;   // behind a fp32-result forward the gradient is fp32
+        if (!set_pitch(L.t[i].gp, gv ? gv[i] : nullptr, t[i].rows, cols, ge) || !set_pitch(L.t[i].op, ov ? ov[i] : nullptr, t[i].rows, cols, oe))
+            return fail(FQ_ERR_SHAPE, "fq_rows_view: negative stride, or more than 2^31 - 1 rows");
+        if (t[i].gx == (const void*)t[i].g && memcmp(&L.t[i].gp, &L.t[i].op, sizeof(RowPitch)) != 0)
+            return fail(FQ_ERR_ARG, "an in-place tensor (gx == g) needs equal views");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (wide_grad) return dtype == FQ_DTYPE_BF16 ? launch_ste_mask_wide<BF16>(L, cols, lo, hi, st) : launch_ste_mask_wide<F16>(L, cols, lo, hi, st);
     switch (dtype) {
@@ -237,6 +298,22 @@ FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, fl
         case FQ_DTYPE_F16: return launch_ste_mask<F16>(L, cols, lo, hi, st);
         default: return launch_ste_mask<BF16>(L, cols, lo, hi, st);
     }
+}
+
+FQ_API int fq_ste_bwd_mask_multi(int n, const fq_bwd_tensor* t, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream) {
+    return ste_bwd_mask_multi_impl(n, t, nullptr, nullptr, cols, lo, hi, dtype, wide_grad, stream);
+}
+
+FQ_API int fq_ste_bwd_mask_multi_v(int n, const fq_bwd_tensor_v* tv, int64_t cols, float lo, float hi, int dtype, int wide_grad, void* stream) {
+    if (n < 1 || n > 1 + MAX_MORE || !tv) return fail(FQ_ERR_ARG, "a launch takes 1 to %d tensors", 1 + MAX_MORE);
+    fq_bwd_tensor t[1 + MAX_MORE];
+    const fq_rows_view *gv[1 + MAX_MORE], *ov[1 + MAX_MORE];
+    for (int i = 0; i < n; ++i) {
+        t[i] = fq_bwd_tensor{tv[i].g, tv[i].gx, tv[i].rows, tv[i].row_bounds, tv[i].mask};
+        gv[i] = &tv[i].gv;
+        ov[i] = &tv[i].gxv;
+    }
+    return ste_bwd_mask_multi_impl(n, t, gv, ov, cols, lo, hi, dtype, wide_grad, stream);
 }
 
 FQ_API int fq_ste_bwd_mask_pair(const void* g0, void* gx0, int64_t rows0, const float* row_bounds0, const void* mask0,
@@ -333,6 +410,26 @@ FQ_API int fq_ste_bwd_rows(const void* g, const void* x, void* gx, int64_t rows,
         case FQ_DTYPE_F32: return launch_ste_rows<F32>(g, x, gx, rows, cols, lo, hi, row_bounds, st);
         case FQ_DTYPE_F16: return launch_ste_rows<F16>(g, x, gx, rows, cols, lo, hi, row_bounds, st);
         default: return launch_ste_rows<BF16>(g, x, gx, rows, cols, lo, hi, row_bounds, st);
+    }
+}
+
+FQ_API int fq_ste_bwd_v(const void* g, const fq_rows_view* gv, const void* x, const fq_rows_view* xv, void* gx, const fq_rows_view* gxv, int64_t rows,
+                        int64_t cols, float lo, float hi, const float* row_bounds, int dtype, void* stream) {
+    if (dtype < 0 || dtype > 2) return fail(FQ_ERR_DTYPE, "unknown dtype code %d", dtype);
+    if (rows < 0 || cols < 0) return fail(FQ_ERR_SHAPE, "negative shape");
+    if (rows == 0 || cols == 0) return ok();
+    if (!g || !x || !gx) return fail(FQ_ERR_NULL, "g / x / gx must not be NULL");
+    StePitch3 p{};
+    const int es = esize_of(dtype);
+    if (!set_pitch(p.g, gv, rows, cols, es) || !set_pitch(p.x, xv, rows, cols, es) || !set_pitch(p.o, gxv, rows, cols, es))
+        return fail(FQ_ERR_SHAPE, "fq_rows_view: negative stride, or more than 2^31 - 1 rows");
+    lo = host_rb(lo, dtype);
+    hi = host_rb(hi, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case FQ_DTYPE_F32: return launch_ste_rows<F32>(g, x, gx, rows, cols, lo, hi, row_bounds, st, p);
+        case FQ_DTYPE_F16: return launch_ste_rows<F16>(g, x, gx, rows, cols, lo, hi, row_bounds, st, p);
+        default: return launch_ste_rows<BF16>(g, x, gx, rows, cols, lo, hi, row_bounds, st, p);
     }
 }
 

@@ -87,16 +87,17 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     } else {
         constexpr int EPV = 8;
         const bool pair = a.n_more > 0;
-        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u);
+        const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u) && pitches_aligned(a, 15, 15);
         const int64_t nvec = a.cols / EPV;
         const int64_t big_rows = largest_rows(a);
         const int64_t bytes = big_rows * a.cols * T::ESIZE;
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
+        const bool pitched = any_pitch(a);
         if constexpr (AC == 2) {
             // fp32 result: 8-byte loads / 16-byte stores keep both streams fully coalesced
             const int64_t nh = a.cols / 4;
             const bool wide_ok = aligned16(a.y) && (reinterpret_cast<uintptr_t>(a.x) & 7u) == 0 && a.cols % 4 == 0 && nh <= 1024 * 8 &&
-                                 more_aligned(a, 7u, 15u);
+                                 more_aligned(a, 7u, 15u) && pitches_aligned(a, 7, 15);
             if (wide_ok) {
                 const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define W(TPR)                                                                                          \
@@ -132,6 +133,7 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
             if (a.cols <= 1024) FQ_LAUNCH((row_generic_kernel<DT, 64, false, AC>), (a.rows + 3) / 4, 256, st, a);
             else FQ_LAUNCH((row_generic_kernel<DT, 256, false, AC>), a.rows, 256, st, a);
         } else {  // very long rows (layerwise): two passes -- |x| max per row through atomics, then apply
+            if (pitched) return fail(FQ_ERR_UNSUPPORTED, "rows that do not follow one another: not served by the two-pass path");
             if (!ws || wsb < (size_t)a.rows * 8)
                 return fail(FQ_ERR_WORKSPACE, "two-pass path needs %zu workspace bytes, got %zu", (size_t)a.rows * 8, wsb);
             if (hipMemsetAsync(ws, 0, (size_t)a.rows * 8, st) != hipSuccess) return fail(FQ_ERR_LAUNCH, "hipMemsetAsync failed");
@@ -159,10 +161,11 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
     seal_slots(a);
     constexpr int EPV = 16 / T::ESIZE;
     const bool pair = a.n_more > 0;  // several tensors in one launch: register kernels only
-    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u);
+    const bool vec_ok = aligned16(a.x) && aligned16(a.y) && (a.cols % EPV == 0) && more_aligned(a, 15u, 15u) && pitches_aligned(a, 15, 15);
     const int64_t nvec = a.cols / EPV;
     const int64_t big_rows = largest_rows(a);
     const int64_t bytes = big_rows * a.cols * T::ESIZE;  // cache policy follows the larger tensor
+    const bool pitched = any_pitch(a);
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
     bool two_pass = false, two_pass_vec = false;
     if (pair && !(vec_ok && nvec <= REG_MAX_VEC)) return fail(FQ_ERR_UNSUPPORTED, "pair launch: rows must be 16-byte aligned and fit the register kernels");
@@ -175,7 +178,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         else launch_reg<DT, ASYM, FAST, false, true, false>(a, nvec, st);
     } else if (a.mask) {
         return fail(FQ_ERR_UNSUPPORTED, "STE-mask forward needs 16-byte aligned rows that fit the register kernels");
-    } else if (vec_ok) {
+    } else if (vec_ok && !pitched) {
         two_pass = two_pass_vec = true;
     } else if (a.cols <= GENERIC_MAX_COLS) {
         if (a.rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows=%lld exceeds the grid limit", (long long)a.rows);
@@ -185,6 +188,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         two_pass = true;
     }
     if (two_pass) {
+        if (pitched) return fail(FQ_ERR_UNSUPPORTED, "rows that do not follow one another: not served by the two-pass path");
         if (!ws || wsb < (size_t)a.rows * 8)
             return fail(FQ_ERR_WORKSPACE, "two-pass path needs %zu workspace bytes, got %zu", (size_t)a.rows * 8, wsb);
         const int64_t ch = two_pass_vec ? tp_chunk_elems<DT, true>() : tp_chunk_elems<DT, false>();
@@ -239,12 +243,16 @@ template <int DT> int launch_ste(const void* g, const void* x, void* gx, int64_t
 
 template <int DT>
 int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi, const float* bounds,
-                    hipStream_t st) {
+                    hipStream_t st, const StePitch3& pitch) {
     using T = Ty<DT>;
     begin_launches();
     constexpr int EPV = 16 / T::ESIZE;
-    if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0))
+    const bool pitched = pitch.g.on || pitch.x.on || pitch.o.on;
+    if (!(aligned16(g) && aligned16(x) && aligned16(gx) && cols % EPV == 0 && pitch_aligned(pitch.g, 15) && pitch_aligned(pitch.x, 15) && pitch_aligned(pitch.o, 15))) {
+        if (pitched) return fail(FQ_ERR_UNSUPPORTED, "rows that do not follow one another: the STE backward needs 16-byte aligned rows of whole vectors");
         return launch_ste<DT>(g, x, gx, rows * cols, lo, hi, st);  // odd layout: plain path, same result
+    }
+    if (pitched && rows > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows exceed the grid limit");
     const int64_t nvec_row = cols / EPV;
     // balanced chunks: every block of a row gets the same number of vectors (<= 256 x 8)
     const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
@@ -255,8 +263,8 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define S(V)                                                                                                                              \
     case V:                                                                                                                               \
-        if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);        \
-        else FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi);           \
+        if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);        \
+        else FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);           \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
 #undef S
@@ -288,8 +296,9 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
     const int64_t mrw = mask_row_words(cols, T::ESIZE);
     if (!mrw) return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: shape not served");
     for (int i = 0; i < L.n; ++i)
-        if (!(aligned16(L.t[i].g) && aligned16(L.t[i].gx) && (reinterpret_cast<uintptr_t>(L.t[i].mask) & 7u) == 0))
-            return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served (g / gx 16 bytes, mask 8 bytes)");
+        if (!(aligned16(L.t[i].g) && aligned16(L.t[i].gx) && (reinterpret_cast<uintptr_t>(L.t[i].mask) & 7u) == 0 && pitch_aligned(L.t[i].gp, 15) &&
+              pitch_aligned(L.t[i].op, 15)))
+            return fail(FQ_ERR_UNSUPPORTED, "STE-mask backward: alignment not served (g / gx rows 16 bytes, mask 8 bytes)");
     const int64_t nvec_row = cols / EPV;
     const int64_t chunks = (nvec_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
     int cv = (int)((nvec_row + chunks - 1) / chunks);
@@ -322,7 +331,8 @@ template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, 
         auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
         if (!mrw || cols > 32768) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: shape not served");
         for (int i = 0; i < L.n; ++i)
-            if (!(aligned16(L.t[i].g) && al8(L.t[i].gx) && al8(L.t[i].mask))) return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
+            if (!(aligned16(L.t[i].g) && al8(L.t[i].gx) && al8(L.t[i].mask) && pitch_aligned(L.t[i].gp, 15) && pitch_aligned(L.t[i].op, 7)))
+                return fail(FQ_ERR_UNSUPPORTED, "fp32-gradient STE backward: alignment not served");
         const int64_t nh_row = cols / 4;
         const int64_t chunks = (nh_row + STE_THREADS * 8 - 1) / (STE_THREADS * 8);
         int ch = (int)((nh_row + chunks - 1) / chunks);
@@ -406,7 +416,7 @@ int launch_w12_rows(const void* w, void* out, void* scale_out, int64_t rows, int
     template int launch_rowwise<DT>(bool, bool, RowArgs, void*, size_t, hipStream_t);                           \
     template int launch_sym_autocast<DT>(bool, RowArgs, void*, size_t, hipStream_t);                                           \
     template int launch_ste<DT>(const void*, const void*, void*, int64_t, float, float, hipStream_t);           \
-    template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t); \
+    template int launch_ste_rows<DT>(const void*, const void*, void*, int64_t, int64_t, float, float, const float*, hipStream_t, const StePitch3&); \
     template int launch_ste_mask<DT>(SteLaunch, int64_t, float, float, hipStream_t);                             \
     template int launch_ste_mask_wide<DT>(SteLaunch, int64_t, float, float, hipStream_t);                        \
     template int launch_w12<DT>(const void*, const void*, void*, int64_t, int64_t, int, int, float, hipStream_t);     \

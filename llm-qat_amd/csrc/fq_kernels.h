@@ -20,6 +20,23 @@
 namespace fq {
 
 constexpr int MAX_MORE = 3;  // up to 4 tensors per launch (q/k/v weights + their shared input)
+
+// Rows that do not follow one another in memory -- "last dim contiguous, rows strided": a slice / chunk() of the last dimension, the
+// transpose(0, 1) of a 3-D tensor (round 5; the reference accepts any strides, utils_quant.py:37).  Row r of the [rows, cols] view is
+// element (r / n_inner, r % n_inner) of a two-level index: it starts `(r / n_inner) * outer + (r % n_inner) * inner` BYTES behind the
+// base pointer.  on == 0 (every model call site): row r starts at r * cols elements and the address arithmetic is what it always was.
+// Block-uniform, so the division is scalar work once per block; rows < 2^31 in pitched mode (host-checked).
+struct RowPitch {
+    int64_t outer, inner;
+    uint32_t n_inner;
+    uint32_t on;
+};
+__device__ __forceinline__ int64_t row_byte_off(int64_t row, int64_t row_bytes, const RowPitch& p) {
+    if (!p.on) return row * row_bytes;
+    const uint32_t r = (uint32_t)row, q = r / p.n_inner;
+    return (int64_t)q * p.outer + (int64_t)(r - q * p.n_inner) * p.inner;
+}
+
 struct TensorSlot {
     int64_t row_begin;
     const void* x;
@@ -27,6 +44,7 @@ struct TensorSlot {
     float* bounds;
     uint64_t* mask;
     float qmax;
+    RowPitch xp, yp;
 };
 
 struct RowArgs {
@@ -54,6 +72,7 @@ struct RowArgs {
     int64_t rows0;
     int n_more;
     TensorSlot more[MAX_MORE];
+    RowPitch xp, yp;   // of the first tensor (x / y); the further tensors carry their own
 };
 
 // STE bit mask: a plain bitmap per row.  Row r starts at mask + r * mask_row_words 64-bit words (mask_row_words =
@@ -180,6 +199,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
     float* bnd = a.bounds;
     uint64_t* msk = a.mask;
     SymConst symk = a.sym;
+    RowPitch xp = a.xp, yp = a.yp;
     if (row >= a.rows0) {
         int64_t rbase = 0;
 #pragma unroll
@@ -191,13 +211,15 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
                 bnd = a.more[i].bounds;
                 msk = a.more[i].mask;
                 symk.qmax = a.more[i].qmax;
+                xp = a.more[i].xp;
+                yp = a.more[i].yp;
             }
         }
         row -= rbase;
     }
     const int nvec = (int)(a.cols / EPV);
-    const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row * a.cols * T::ESIZE);
-    uint4* __restrict__ yr = (uint4*)((char*)yb + row * a.cols * T::ESIZE);
+    const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row_byte_off(row, a.cols * T::ESIZE, xp));
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off(row, a.cols * T::ESIZE, yp));
 
     uint4 r[VPT];
 #pragma unroll
@@ -412,6 +434,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
     float* bnd = a.bounds;
     uint64_t* msk = a.mask;
     float qmax = a.sym.qmax;
+    RowPitch xp = a.xp, yp = a.yp;
     if (row >= a.rows0) {
         int64_t rbase = 0;
 #pragma unroll
@@ -423,13 +446,15 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
                 bnd = a.more[i].bounds;
                 msk = a.more[i].mask;
                 qmax = a.more[i].qmax;
+                xp = a.more[i].xp;
+                yp = a.more[i].yp;
             }
         }
         row -= rbase;
     }
     const int nh = (int)(a.cols / 4);
-    const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row * a.cols * 2);
-    uint4* __restrict__ yr = (uint4*)((char*)yb + row * a.cols * 4);
+    const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row_byte_off(row, a.cols * 2, xp));
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off(row, a.cols * 4, yp));
     uint2 r[HPT];
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
@@ -509,15 +534,17 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
         row = blockIdx.x;
         t = threadIdx.x;
     }
-    const int64_t base = row * a.cols;
+    const int64_t base = row * a.cols;   // (the debug index output is always contiguous)
     const int64_t cols = a.cols;
-    const float first = T::load1(a.x, base);  // cols >= 1 guaranteed by the host
+    const int64_t xbase = row_byte_off(row, cols * T::ESIZE, a.xp) / T::ESIZE;                                       // in elements
+    const int64_t ybase = row_byte_off(row, cols * (AC == 2 ? 4 : T::ESIZE), a.yp) / (AC == 2 ? 4 : T::ESIZE);
+    const float first = T::load1(a.x, xbase);  // cols >= 1 guaranteed by the host
     SymRow sr;
     AsymRow ar;
     if constexpr (!ASYM) {
         uint32_t acc = 0;
         for (int64_t c = t; c < cols; c += TPR) {
-            uint32_t b = as_u(T::load1(a.x, base + c)) & 0x7FFFFFFFu;
+            uint32_t b = as_u(T::load1(a.x, xbase + c)) & 0x7FFFFFFFu;
             acc = acc > b ? acc : b;
         }
         const float m = as_f(block_reduce<OpMaxU, NW>(acc, red[0]));
@@ -534,7 +561,7 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
         float mx = first, mn = first;
         uint32_t acc = 0;
         for (int64_t c = t; c < cols; c += TPR) {
-            float v = T::load1(a.x, base + c);
+            float v = T::load1(a.x, xbase + c);
             mx = __builtin_fmaxf(mx, v);
             mn = __builtin_fminf(mn, v);
             uint32_t b = as_u(v) & 0x7FFFFFFFu;
@@ -557,18 +584,18 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_generic_kernel(RowA
         }
     }
     for (int64_t c = t; c < cols; c += TPR) {
-        const float v = T::load1(a.x, base + c);
+        const float v = T::load1(a.x, xbase + c);
         int32_t* ip = a.idx ? a.idx + base + c : nullptr;
         float o;
         if constexpr (AC != 0) {
             o = sym_elem_autocast(v, sr);
             if constexpr (AC == 2) {
-                ((float*)a.y)[base + c] = o;
+                ((float*)a.y)[ybase + c] = o;
                 continue;
             }
         } else if constexpr (!ASYM) o = sym_elem<DT, false>(v, sr, ip);
         else o = asym_elem<DT>(v, ar, a.asym, ip);
-        T::store1(a.y, base + c, o);
+        T::store1(a.y, ybase + c, o);
     }
 }
 
@@ -825,20 +852,25 @@ __global__ __launch_bounds__(STE_THREADS) void ste_scalar_kernel(const void* __r
 // Row-aware STE: block b handles chunk (b % chunks) of row (b / chunks); a chunk is `cv` vectors
 // (cv <= STE_THREADS * VPT; the host balances chunks so no block is nearly empty).  If the row's
 // recorded bounds are strictly inside (lo, hi) no element can be masked: copy g, never touch x.
+struct StePitch3 {
+    RowPitch g, x, o;   // of grad_output, the forward's input and the result (RowPitch above)
+};
 template <int DT, int VPT, bool NTL = true, bool NTS = true>
 __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __restrict__ g, const void* __restrict__ x,
                                                                void* __restrict__ gx, int64_t nvec_row, int64_t chunks, int cv,
-                                                               const float* __restrict__ bounds, float lo, float hi) {
+                                                               const float* __restrict__ bounds, float lo, float hi, StePitch3 p) {
     const int64_t row = blockIdx.x / chunks;
     const int64_t vs = (blockIdx.x % chunks) * cv;
-    const int64_t off = row * nvec_row + vs;
-    const uint4* gr = (const uint4*)g + off;
-    const uint4* xr = (const uint4*)x + off;
-    uint4* or_ = (uint4*)gx + off;
+    const uint4* gr = (const uint4*)((const char*)g + row_byte_off(row, nvec_row * 16, p.g)) + vs;
+    const uint4* xr = (const uint4*)((const char*)x + row_byte_off(row, nvec_row * 16, p.x)) + vs;
+    uint4* or_ = (uint4*)((char*)gx + row_byte_off(row, nvec_row * 16, p.o)) + vs;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
-    const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
-    const bool safe = (ub < hi) && (lb > lo);  // false when a bound is NaN
+    bool safe = false;   // no recorded bounds (pitched tensors in the plain data flow): every row re-reads x
+    if (bounds) {
+        const float ub = bounds[2 * row], lb = bounds[2 * row + 1];
+        safe = (ub < hi) && (lb > lo);  // false when a bound is NaN
+    }
     const int t = threadIdx.x;
     uint4 rg[VPT];
 #pragma unroll
@@ -1039,6 +1071,7 @@ struct SteSlot {
     int64_t rows;
     int64_t blk_begin;  // first block of this slot
     int inplace;
+    RowPitch gp, op;    // rows of g / gx that do not follow one another (RowPitch above); an in-place slot: gp == op
 };
 struct SteLaunch {
     int n;
@@ -1098,6 +1131,8 @@ __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) 
     FQ_PICK(rows);
     FQ_PICK(blk_begin);
     FQ_PICK(inplace);
+    FQ_PICK(gp);
+    FQ_PICK(op);
 #undef FQ_PICK
     return r;
 }
@@ -1106,11 +1141,11 @@ __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) 
 // the gradient and mask loads have been issued, so that nothing waits on them (null: the caller knows the row can clip).
 template <int DT, int VPT, bool NTL, bool NTS>
 __device__ __forceinline__ void ste_mask_chunk(const void* g, void* gx, const uint8_t* mrow, int mrow_dwords, int64_t row, int64_t nvec_row,
-                                               int64_t vs, int cv, const float* bounds, float lo, float hi, int t) {
+                                               int64_t vs, int cv, const float* bounds, float lo, float hi, int t, const RowPitch& gp,
+                                               const RowPitch& op) {
     using T = Ty<DT>;
-    const int64_t off = row * nvec_row + vs;
-    const uint4* gr = (const uint4*)g + off;
-    uint4* or_ = (uint4*)gx + off;
+    const uint4* gr = (const uint4*)((const char*)g + row_byte_off(row, nvec_row * 16, gp)) + vs;
+    uint4* or_ = (uint4*)((char*)gx + row_byte_off(row, nvec_row * 16, op)) + vs;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
     uint4 rg[VPT];
@@ -1154,7 +1189,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int6
     const int64_t local = (int64_t)blockIdx.x - sl.blk_begin;
     if (!sl.inplace) {
         ste_mask_chunk<DT, VPT, NTL, NTS>(sl.g, sl.gx, (const uint8_t*)(sl.mask + local * mask_row_words), (int)mask_row_words * 2, local, nvec_row,
-                                          (int64_t)blockIdx.y * cv, cv, sl.bounds, lo, hi, t);
+                                          (int64_t)blockIdx.y * cv, cv, sl.bounds, lo, hi, t, sl.gp, sl.op);
         return;
     }
     if (blockIdx.y) return;  // an in-place slot's blocks walk whole rows
@@ -1177,7 +1212,8 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int6
             const uint8_t* mrow = (const uint8_t*)(sl.mask + row * mask_row_words);
 #pragma unroll 1
             for (int c = 0; c < (int)gridDim.y; ++c)
-                ste_mask_chunk<DT, VPT, false, false>(sl.g, sl.gx, mrow, (int)mask_row_words * 2, row, nvec_row, (int64_t)c * cv, cv, nullptr, lo, hi, t);
+                ste_mask_chunk<DT, VPT, false, false>(sl.g, sl.gx, mrow, (int)mask_row_words * 2, row, nvec_row, (int64_t)c * cv, cv, nullptr, lo, hi, t,
+                                                      sl.gp, sl.op);
         }
     }
 }
@@ -1195,9 +1231,8 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(SteLaunch L,
     const SteSlot sl = ste_pick_slot(L, (int64_t)blockIdx.x);
     const int64_t row = (int64_t)blockIdx.x - sl.blk_begin;
     const int64_t hs = (int64_t)blockIdx.y * ch;
-    const int64_t off = row * nh_row + hs;
-    const uint4* gr = (const uint4*)sl.g + off;
-    uint2* or_ = (uint2*)sl.gx + off;
+    const uint4* gr = (const uint4*)((const char*)sl.g + row_byte_off(row, nh_row * 16, sl.gp)) + hs;   // fp32 gradient: 16 bytes per lane
+    uint2* or_ = (uint2*)((char*)sl.gx + row_byte_off(row, nh_row * 8, sl.op)) + hs;                    // 16-bit result: 8 bytes per lane
     const int64_t rem = nh_row - hs;
     const int nh = (int)(rem < ch ? rem : ch);
     const int t = threadIdx.x;

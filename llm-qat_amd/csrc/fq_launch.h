@@ -48,6 +48,18 @@ inline int launch_result() {
 #define FQ_LAUNCHK(kern, grid, block, shmem, st, ...) ::fq::launch(kern, grid, block, st, __VA_ARGS__)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// pitched rows (RowPitch): every row start must keep the alignment the vector kernels assume
+inline bool pitch_aligned(const RowPitch& p, int64_t mask) { return !p.on || (((p.outer | p.inner) & mask) == 0); }
+inline bool pitches_aligned(const RowArgs& a, int64_t xmask, int64_t ymask) {
+    bool ok = pitch_aligned(a.xp, xmask) && pitch_aligned(a.yp, ymask);
+    for (int i = 0; i < a.n_more; ++i) ok = ok && pitch_aligned(a.more[i].xp, xmask) && pitch_aligned(a.more[i].yp, ymask);
+    return ok;
+}
+inline bool any_pitch(const RowArgs& a) {
+    bool on = a.xp.on || a.yp.on;
+    for (int i = 0; i < a.n_more; ++i) on = on || a.more[i].xp.on || a.more[i].yp.on;
+    return on;
+}
 // the further tensors of a multi-tensor launch: alignment of their x / y, and the rows of the largest tensor (its size
 // decides the cache policy of the launch)
 inline bool more_aligned(const RowArgs& a, uintptr_t xmask, uintptr_t ymask) {
@@ -201,6 +213,6 @@ inline uint32_t ste_clip_key(float lo, float hi, int dtype) {
 }
 template <int DT>
 FQ_HIDDEN int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_t cols, float lo, float hi,
-                              const float* bounds, hipStream_t st);
+                              const float* bounds, hipStream_t st, const StePitch3& pitch = StePitch3{});
 
 }  // namespace fq

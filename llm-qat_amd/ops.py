@@ -148,6 +148,43 @@ def _empty_input(what, x, layerwise):
         raise IndexError(f"{what}: max(): Expected reduction dim {x.dim() - 1} to have non-zero size.")
 
 
+# ---- rows that do not follow one another in memory ("last dim contiguous, rows strided": slices, chunk(), transpose(0, 1) of a 3-D tensor)
+# are served IN the kernels (the C ABI's fq_rows_view, ABI 5): no .contiguous() in front of the launch, no copy_ behind it, and the result
+# keeps the layout the reference's elementwise ops give it (torch.empty_like's rule: the input's strides when it is dense, else contiguous).
+# Anything else that is not contiguous -- a strided LAST dimension, 4-D views, layerwise -- keeps the copy path.
+def rows_view(t, layerwise=False):
+    """-> None: contiguous (no view needed) | (n_inner, stride_outer, stride_inner) in elements | False: needs a copy"""
+    if t.is_contiguous():
+        return None
+    nd = t.dim()
+    if layerwise or nd < 2 or nd > 3 or t.shape[-1] < 2 or t.stride(-1) != 1:
+        return False
+    if nd == 2:
+        return (t.shape[0], 0, t.stride(0))
+    return (t.shape[1], t.stride(0), t.stride(1))
+
+
+def check_4d(x, layerwise):
+    """the reference flattens a 4-D input with `input.view(d0, d1, -1)` (models/utils_quant.py:63 / :127): a layout for which that view does
+    not exist raises there -- and here, with torch's own exception, instead of being served through a copy"""
+    if x.dim() == 4 and not layerwise and not x.is_contiguous():
+        x.view(x.shape[0], x.shape[1], -1)
+
+
+def _rv(v):
+    return _lib.RowsView(*v) if v else _lib.RowsView(0, 0, 0)
+
+
+def _strided_out(x, dtype=None):
+    """the result tensor for a strided input and its view: empty_like keeps a dense input's strides and makes everything else contiguous,
+    exactly what the reference's elementwise ops (TensorIterator) do"""
+    y = torch.empty_like(x) if dtype is None else torch.empty_like(x, dtype=dtype)
+    return y, rows_view(y)
+
+
+_views_served = 0   # launches that took a view instead of a copy (tests read it)
+
+
 def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     what = f"{kind}_quantize"
     code = _prep(x, what)
@@ -155,9 +192,23 @@ def _rowwise(kind, x, num_bits, layerwise, want_bounds, debug):
     if x.numel() == 0:
         _empty_input(what, x, layerwise)
         return torch.empty_like(x), None, None, None
+    check_4d(x, layerwise)
+    L = _lib.lib()
+    xv = rows_view(x, layerwise)
+    if xv and not debug and code != _lib.DTYPE_F64:   # strided rows: served in the kernel
+        y, yv = _strided_out(x)
+        if yv is not False:
+            bounds = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if want_bounds else None
+            with _DeviceOf(x):
+                rc = L.fq_rowwise_fwd_v(1 if kind == "asym" else 0, x.data_ptr(), _rv(xv), y.data_ptr(), _rv(yv), rows, cols, int(num_bits), code, _semantics,
+                                        0.0, 0.0, bounds.data_ptr() if want_bounds else None, None, 0, _stream(x))
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, what)
+                global _views_served
+                _views_served += 1
+                return y, bounds, None, None
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty_like(xc)
-    L = _lib.lib()
     ws_bytes = _ws_bytes(rows, cols, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     ws_ptr = ws.data_ptr() if ws is not None else None
@@ -212,13 +263,35 @@ def train_forward(kind, x, num_bits, layerwise, lo, hi):
     code = _DTYPES.get(x.dtype)
     if code is None:
         _prep(x, f"{kind}_quantize")
-    if not x.is_contiguous() or x.numel() == 0:
+    if x.numel() == 0:
         return None
+    xv = None
+    if not x.is_contiguous():
+        check_4d(x, layerwise)
+        xv = rows_view(x, layerwise)
+        if not xv:
+            return None
     rows, cols = rows_cols(tuple(x.shape), layerwise)
     mbytes = _mask_bytes(rows, cols, code)
     if not mbytes:
         return None
     L = _lib.lib()
+    if xv:   # strided rows: served in the kernel (the side buffer is indexed by row number and stays dense)
+        y, yv = _strided_out(x)
+        if yv is False:
+            return None
+        side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
+        sp = side.data_ptr()
+        with _DeviceOf(x):
+            rc = L.fq_rowwise_fwd_v(1 if kind == "asym" else 0, x.data_ptr(), _rv(xv), y.data_ptr(), _rv(yv), rows, cols, int(num_bits), code, _semantics,
+                                    lo, hi, sp, sp + rows * 8, mbytes, _stream(x))
+        if rc:
+            if rc == _lib.ERR_UNSUPPORTED:
+                return None
+            _lib.check(rc, f"{kind}_quantize_train")
+        global _views_served
+        _views_served += 1
+        return y, side, rows, cols
     y = torch.empty_like(x)
     side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
     sp = side.data_ptr()
@@ -237,12 +310,44 @@ def train_forward(kind, x, num_bits, layerwise, lo, hi):
     return y, side, rows, cols
 
 
+def _mask_backward_v(gs, sides, rows, cols, lo, hi, code, wide, inplace=None, out_dtype=None):
+    """fq_ste_bwd_mask_multi_v over 1..2 gradients of which at least one has strided rows -> [gx] or None (not served: copy path)"""
+    n = len(gs)
+    arr = (_lib.BwdTensorV * n)()
+    outs = []
+    for i, (g, sd, r) in enumerate(zip(gs, sides, rows)):
+        gv = rows_view(g)
+        if gv is False or g.data_ptr() & 15:
+            return None
+        if inplace and inplace[i]:
+            o, ov = g, gv
+        else:
+            o, ov = _strided_out(g, out_dtype)
+            if ov is False:
+                return None
+        outs.append(o)
+        sp = sd.data_ptr()
+        arr[i] = _lib.BwdTensorV(g.data_ptr(), o.data_ptr(), r, sp, sp + r * 8, _rv(gv), _rv(ov))
+    with _DeviceOf(gs[0]):
+        rc = _lib.lib().fq_ste_bwd_mask_multi_v(n, arr, cols, float(lo), float(hi), code, 1 if wide else 0, _stream(gs[0]))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "ste_backward_mask[strided]")
+    global _views_served
+    _views_served += 1
+    return outs
+
+
 def train_backward(grad_output, side, rows, cols, lo, hi, inplace=False):
     """inplace: mask the gradient where it stands and return it (fq_ste_bwd_mask with gx == g): rows that cannot clip are
     not touched, so a weight's gradient costs a launch and no traffic.  Only for callers that own grad_output exclusively."""
     code = _DTYPES.get(grad_output.dtype)
     if code is None or grad_output.device.type != "cuda":
         _prep(grad_output, "ste_backward")
+    if not grad_output.is_contiguous() and grad_output.numel():   # strided rows: masked in the kernel, no .contiguous() copy
+        res = _mask_backward_v([grad_output], [side], [rows], cols, lo, hi, code, False, [inplace])
+        if res is not None:
+            return res[0]
     g = _aligned(grad_output)
     gx = g if inplace else torch.empty_like(g)
     sp = side.data_ptr()
@@ -265,6 +370,10 @@ def train_backward_wide(grad_output, side, rows, cols, lo, hi, out_dtype):
     code = _DTYPES.get(out_dtype)
     if code is None or grad_output.device.type != "cuda":
         raise TypeError(f"ste_backward[wide]: unsupported input dtype {out_dtype} / device {grad_output.device}")
+    if grad_output.dtype == torch.float32 and not grad_output.is_contiguous() and grad_output.numel():
+        res = _mask_backward_v([grad_output], [side], [rows], cols, lo, hi, code, True, None, out_dtype)
+        if res is not None:
+            return res[0]
     g = _aligned(grad_output if grad_output.dtype == torch.float32 else grad_output.float())
     gx = torch.empty(g.shape, dtype=out_dtype, device=g.device)
     sp = side.data_ptr()
@@ -298,9 +407,31 @@ def sym_forward_autocast(x, num_bits, layerwise, wide, lo=-2.0, hi=2.0, train=No
     if x.numel() == 0:
         _empty_input("sym_quantize[autocast]", x, layerwise)
         return torch.empty(x.shape, dtype=torch.float32 if wide else x.dtype, device=x.device), None, rows, cols, None
+    check_4d(x, layerwise)
+    L = _lib.lib()
+    xv = rows_view(x, layerwise)
+    if xv:   # strided rows: served in the kernel (register-kernel shapes; anything else takes the copy path below)
+        mbytes = _mask_bytes(rows, cols, code)
+        y, yv = _strided_out(x, torch.float32 if wide else x.dtype)
+        if mbytes and yv is not False:
+            side = got = None
+            bp = mp = None
+            if train == "mask":
+                side = torch.empty(rows * 8 + mbytes, dtype=torch.uint8, device=x.device)
+                bp, mp, got = side.data_ptr(), side.data_ptr() + rows * 8, "mask"
+            elif train == "bounds":
+                side = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+                bp, got = side.data_ptr(), "bounds"
+            arr = (_lib.FwdTensorV * 1)(_lib.FwdTensorV(x.data_ptr(), y.data_ptr(), rows, int(num_bits), bp, mp, mbytes if mp else 0, _rv(xv), _rv(yv)))
+            with _DeviceOf(x):
+                rc = L.fq_sym_fwd_multi_v(1, arr, cols, code, _SEM_AUTOCAST, 2 if wide else 1, float(lo), float(hi), _stream(x))
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "sym_quantize[autocast]")
+                global _views_served
+                _views_served += 1
+                return y, side, rows, cols, got
     xc = x if x.is_contiguous() else x.contiguous()
     y = torch.empty(xc.shape, dtype=torch.float32 if wide else x.dtype, device=x.device)
-    L = _lib.lib()
     side, got = None, None
     ws_bytes = _ws_bytes(rows, cols, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
@@ -339,8 +470,13 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     misaligned, non-contiguous, rows too long): use two calls then.
     side_* (row bounds + STE mask, as in train_forward) is produced only for the operands that need a gradient.
     wide: under autocast, return the reference's fp32 results (else those rounded once to the operand dtype)."""
-    if w.dtype != x.dtype or w.device != x.device or not (w.is_cuda and w.is_contiguous() and x.is_contiguous()):
+    if w.dtype != x.dtype or w.device != x.device or not w.is_cuda:
         return None
+    wv = xv = None
+    if not (w.is_contiguous() and x.is_contiguous()):   # strided rows of either operand: served in the kernel where the view allows it
+        wv, xv = rows_view(w), rows_view(x)
+        if wv is False or xv is False:
+            return None
     code = _DTYPES.get(w.dtype)
     if code is None or not (1 <= w.dim() <= 3 and 1 <= x.dim() <= 3) or x.shape[-1] != w.shape[-1] or x.numel() == 0 or w.numel() == 0:
         return None
@@ -354,13 +490,28 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     if ac and not wide and not autocast_narrow_ok(w):
         return None  # autocast dtype != operand dtype: the two-call path returns fp32 results, F.linear rounds once
     L = _lib.lib()
+    side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device) if need_w else None
+    side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device) if need_x else None
+    pw, px = (side_w.data_ptr() if need_w else None), (side_x.data_ptr() if need_x else None)
+    if wv or xv:
+        (wq, wqv), (xq, xqv) = _strided_out(w, torch.float32 if wide else None), _strided_out(x, torch.float32 if wide else None)
+        if wqv is False or xqv is False:
+            return None
+        arr = (_lib.FwdTensorV * 2)(
+            _lib.FwdTensorV(w.data_ptr(), wq.data_ptr(), rows_w, w_bits, pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0, _rv(wv), _rv(wqv)),
+            _lib.FwdTensorV(x.data_ptr(), xq.data_ptr(), rows_x, a_bits, px, px + rows_x * 8 if need_x else None, mx if need_x else 0, _rv(xv), _rv(xqv)))
+        rc = _on_device(w, lambda st: L.fq_sym_fwd_multi_v(2, arr, cols, code, _SEM_AUTOCAST if ac else _semantics, (2 if wide else 1) if ac else 0, lo, hi, st))
+        if rc:
+            if rc == _lib.ERR_UNSUPPORTED:
+                return None
+            _lib.check(rc, "quantize_pair[strided]")
+        global _views_served
+        _views_served += 1
+        return wq, xq, side_w, side_x, rows_w, rows_x, cols
     if wide:
         wq, xq = torch.empty(w.shape, dtype=torch.float32, device=w.device), torch.empty(x.shape, dtype=torch.float32, device=w.device)
     else:
         wq, xq = torch.empty_like(w), torch.empty_like(x)
-    side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device) if need_w else None
-    side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device) if need_x else None
-    pw, px = (side_w.data_ptr() if need_w else None), (side_x.data_ptr() if need_x else None)
     rc = _on_device(w, lambda st: L.fq_sym_fwd_pair(
         w.data_ptr(), wq.data_ptr(), rows_w, w_bits, pw, pw + rows_w * 8 if need_w else None, mw if need_w else 0,
         x.data_ptr(), xq.data_ptr(), rows_x, a_bits, px, px + rows_x * 8 if need_x else None, mx if need_x else 0,
@@ -398,6 +549,10 @@ def pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, lo, hi, inplace_
             return train_backward(gw, side_w, rows_w, cols, lo, hi, inplace=inplace_w), None
         return None, train_backward(gx, side_x, rows_x, cols, lo, hi)
     code = _DTYPES.get(gw.dtype)
+    if not (gw.is_contiguous() and gx.is_contiguous()):   # strided rows: masked in the kernel
+        res = _mask_backward_v([gw, gx], [side_w, side_x], [rows_w, rows_x], cols, lo, hi, code, False, [inplace_w, False])
+        if res is not None:
+            return res[0], res[1]
     gw, gx = _aligned(gw), _aligned(gx)
     ow, ox = (gw if inplace_w else torch.empty_like(gw)), torch.empty_like(gx)
     pw, px = side_w.data_ptr(), side_x.data_ptr()
@@ -595,12 +750,26 @@ def ste_backward(grad_output, x, lo, hi, row_bounds=None, rows_cols_hint=None):
         raise RuntimeError(f"ste_backward: shape mismatch {tuple(grad_output.shape)} vs {tuple(x.shape)}")
     if grad_output.dtype != x.dtype:  # cannot happen through the autograd Functions (output dtype == input dtype)
         raise NotImplementedError(f"ste_backward: grad dtype {grad_output.dtype} != input dtype {x.dtype}")
+    L = _lib.lib()
+    if not (grad_output.is_contiguous() and x.is_contiguous()) and grad_output.numel() and code != _lib.DTYPE_F64:
+        gv, xv = rows_view(grad_output), rows_view(x)   # strided rows of the gradient and / or the saved input: served in the kernel
+        if gv is not False and xv is not False:
+            gx, ov = _strided_out(grad_output)
+            if ov is not False:
+                rows, cols = rows_cols(tuple(x.shape), False)
+                with _DeviceOf(x):
+                    rc = L.fq_ste_bwd_v(grad_output.data_ptr(), _rv(gv), x.data_ptr(), _rv(xv), gx.data_ptr(), _rv(ov), rows, cols, float(lo), float(hi),
+                                        None, code, _stream(x))
+                if rc != _lib.ERR_UNSUPPORTED:
+                    _lib.check(rc, "ste_backward[strided]")
+                    global _views_served
+                    _views_served += 1
+                    return gx
     g = grad_output if grad_output.is_contiguous() else grad_output.contiguous()
     xc = x if x.is_contiguous() else x.contiguous()
     gx = torch.empty_like(g)
     if g.numel() == 0:
         return gx
-    L = _lib.lib()
     with _DeviceOf(x):
         if row_bounds is not None:
             rows, cols = rows_cols_hint

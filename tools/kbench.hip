@@ -516,13 +516,13 @@ int main(int argc, char** argv) {
     if (vpt == V)                                                                                                                     \
         report("ste_rows<VPT=" #V ",NT=" #NT "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                            \
                    hipLaunchKernelGGL((ste_rows_kernel<BF16, V, NT, NT>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
-                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI);                       \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI, StePitch3{});                       \
                }, IT));
 #define STERM(V, LO, HI, LABEL)                                                                                                      \
     if (vpt == V)                                                                                                                     \
         report("ste_rows<VPT=" #V ",NTL=0,NTS=1> " LABEL, 3.0 * bytes, time_it([&](int i) {                                          \
                    hipLaunchKernelGGL((ste_rows_kernel<BF16, V, false, true>), dim3((unsigned)(rows * chunks)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
-                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI);                       \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, chunks, cv, b.bounds[i % NS], LO, HI, StePitch3{});                       \
                }, IT));
         STERM(6, -2.0f, 2.0f, "all rows safe") STERM(6, -1e-3f, 1e-3f, "no row safe") STERM(2, -2.0f, 2.0f, "all rows safe") STERM(2, -1e-3f, 1e-3f, "no row safe")
         STER(6, false, -2.0f, 2.0f, "all rows safe") STER(6, true, -2.0f, 2.0f, "all rows safe")
@@ -533,7 +533,7 @@ int main(int argc, char** argv) {
         const int64_t ch2 = (nv_row + CV - 1) / CV;                                                                                   \
         report("ste_rows<VPT=" #V ",NT=1,cv=" #CV "> " LABEL, 3.0 * bytes, time_it([&](int i) {                                        \
                    hipLaunchKernelGGL((ste_rows_kernel<BF16, V, true, true>), dim3((unsigned)(rows * ch2)), dim3(STE_THREADS), 0, 0, b.g[i % NS], \
-                                      b.x[i % NS], b.gx[i % NS], nv_row, ch2, CV, b.bounds[i % NS], LO, HI);                          \
+                                      b.x[i % NS], b.gx[i % NS], nv_row, ch2, CV, b.bounds[i % NS], LO, HI, StePitch3{});                          \
                }, IT));                                                                                                               \
     }
         STERC(1, 256, -1e-3f, 1e-3f, "no row safe") STERC(2, 512, -1e-3f, 1e-3f, "no row safe") STERC(3, 768, -1e-3f, 1e-3f, "no row safe")

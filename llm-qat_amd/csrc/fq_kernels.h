@@ -32,6 +32,9 @@ struct RowPitch {
     uint32_t on;
 };
 __device__ __forceinline__ int64_t row_byte_off(int64_t row, int64_t row_bytes, const RowPitch& p) {
+#ifdef FQ_AB_NO_PITCH   // A/B build only (tools/ab_bench.sh): the address arithmetic of rounds 1-4, to price the pitch branch
+    return row * row_bytes;
+#endif
     if (!p.on) return row * row_bytes;
     const uint32_t r = (uint32_t)row, q = r / p.n_inner;
     return (int64_t)q * p.outer + (int64_t)(r - q * p.n_inner) * p.inner;

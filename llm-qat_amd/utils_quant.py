@@ -673,46 +673,51 @@ def pair_operands(flag=True):
 
 
 class _PairNode(torch.autograd.Function):
-    """Autograd node over a QuantizeLinear's two operands: the results of one ops.pair_forward launch, or a weight's own launch + an
+    """Autograd node over a QuantizeLinear's two operands: the results of one two-tensor launch, or a weight's own launch + an
     activation a sibling has already fake-quantized.  The two results have one consumer, that module's F.linear, and so live or die
-    together.  (K and V of the KV hooks share a forward launch but never a node.)"""
+    together.  (K and V of the KV hooks share a forward launch but never a node.)  The clip is the module's own literal [-2, 2]."""
 
     @staticmethod
-    def forward(ctx, weight, input, res, clip=(-2.0, 2.0), weight_first=False, shared_x=False):
-        wq, xq, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols = res
-        ctx.dtype, ctx.clip, ctx.fq_st = weight.dtype, clip, _state().ref
-        ctx.inplace_w = bool(weight_first)  # tensor 0 is a QuantizeLinear's weight: its gradient may be handed on by reference
+    def forward(ctx, weight, input, res, code, view_x):
+        wq, xq, side_w, side_x, rows_w, rows_x, cols = res
+        ctx.fq = (rows_w, rows_x, cols, code, weight.dtype, _state().ref)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
-        # (wq / xq are fresh tensors of the launch that nothing else refers to: they become this node's outputs as they are -- unless
-        # xq is remembered for the sibling projections: then this node gets a tensor of its own over the same data)
-        if shared_x:
+        # (wq / xq are fresh tensors of the launch that nothing else refers to and become this node's outputs as they are; an xq that a
+        # sibling made is plain data, or the output of that sibling's node: this node gets a tensor of its own over the same memory)
+        if view_x:
             xq = xq.view_as(xq)
         # An operand that needs no gradient (frozen weight, input without grad) gets a result that needs none either, as
         # SymQuantizer.apply gives in the reference: F.linear's backward then skips the wgrad / dgrad GEMM it would
         # otherwise run only for this node to throw the result away.
-        nd = [t for t, need in ((wq, ctx.needs_input_grad[0]), (xq, ctx.needs_input_grad[1])) if not need]
-        if nd:
-            ctx.mark_non_differentiable(*nd)
+        nw, nx = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (nw and nx):
+            ctx.mark_non_differentiable(*[t for t, need in ((wq, nw), (xq, nx)) if not need])
         return wq, xq
 
     @staticmethod
     @_graph_aware
     def backward(ctx, gw, gx):
-        inplace_w = ctx.inplace_w and _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
-        _backward_started(ctx.fq_st)
-        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        lo, hi = ctx.clip
+        # (runs on the autograd engine's device thread, where every line of Python costs 2-3x what it costs on the caller's:
+        # tools/host_pieces.py -- hence the straight-line fast path for the ordinary case)
+        inplace_w = _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
+        rows_w, rows_x, cols, code, dtype, st = ctx.fq
+        _backward_started(st)
         side_w, side_x = ctx.saved_tensors
-        if need_w and gw is not None and gw.dtype != ctx.dtype:
-            gw, inplace_w = gw.to(ctx.dtype), ctx.inplace_w and _INPLACE_WGRAD   # a fresh tensor of our own
+        if gw is not None and gx is not None and gw.dtype is dtype and gx.dtype is dtype and side_w is not None and side_x is not None:
+            out = ops.pair_backward_planned(gw, gx, side_w, side_x, rows_w, rows_x, cols, code, inplace_w)
+            if out is not None:
+                return out[0], out[1], None, None, None
+        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_w and gw is not None and gw.dtype != dtype:
+            gw, inplace_w = gw.to(dtype), _INPLACE_WGRAD   # a fresh tensor of our own
         elif not need_w:
             gw = None
-        gx = gx.to(ctx.dtype) if (need_x and gx is not None and gx.dtype != ctx.dtype) else (gx if need_x else None)
+        gx = gx.to(dtype) if (need_x and gx is not None and gx.dtype != dtype) else (gx if need_x else None)
         if gw is None and gx is None:
-            return None, None, None, None, None, None
-        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, ctx.rows_w, ctx.rows_x, ctx.cols, lo, hi, inplace_w=inplace_w)
-        return ow, ox, None, None, None, None
+            return None, None, None, None, None
+        ow, ox = ops.pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, -2.0, 2.0, inplace_w=inplace_w)
+        return ow, ox, None, None, None
 
 
 def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
@@ -938,6 +943,8 @@ class _PrecomputedAct(torch.autograd.Function):
 
 
 class QuantizeLinear(nn.Linear):
+    _fq_plan = None   # (input shape, input dtype, weight dtype, ops.pair_plan): the launch plan of the last input shape (a plain attribute)
+
     def __init__(self, *kargs, symmetric=True, bias=False, w_bits=32, a_bits=32, act_layerwise=False,
                  weight_layerwise=False):
         super().__init__(*kargs, bias=False)  # `bias` is accepted and ignored, as in the reference (:176)
@@ -946,7 +953,7 @@ class QuantizeLinear(nn.Linear):
         self.act_layerwise = act_layerwise
         self.weight_layerwise = weight_layerwise
         if 2 < self.a_bits < 32:
-            self.act_quantizer = SymQuantizer if symmetric else AsymQuantizer
+            self.act_quantizer = SymQuantizer if symmetric else AsymQuantizer   # (attribute absent otherwise, as in the reference :184-188)
         self._act_kind = "sym" if symmetric else "asym"  # what torch.compile's trace reads (a class identity test does not trace)
 
     def _low_bit_weight(self, w):
@@ -1013,8 +1020,61 @@ class QuantizeLinear(nn.Linear):
     def _pair_forward(self, input_):
         """weight and input of this module under ONE autograd node: both in one launch, or -- when a sibling projection has already
         fake-quantized this input -- the weight's own launch + the remembered activation.  None when not applicable (then the ordinary
-        two calls run)."""
-        if not (_PAIR and _BACKWARD_MODE == "mask" and 3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
+        two calls run).  What depends only on shapes / dtype / device is decided once per module and input shape (`ops.pair_plan`)."""
+        if not (_PAIR and _BACKWARD_MODE == "mask"):
+            return None
+        weight = self.weight
+        plan = self._fq_plan
+        if plan is None or plan[0] != input_.shape or plan[1] is not input_.dtype or plan[2] is not weight.dtype:
+            ok = (3 <= self.w_bits < 32 and 2 < self.a_bits < 32 and getattr(self, "act_quantizer", None) is SymQuantizer and not self.act_layerwise
+                  and not self.weight_layerwise)
+            plan = self._fq_plan = (input_.shape, input_.dtype, weight.dtype, ops.pair_plan(weight, input_) if ok else None)
+        pp = plan[3]
+        if pp is None or _WEIGHT_CACHE or not (weight.is_contiguous() and input_.is_contiguous()) or input_.is_inference() or weight.is_inference():
+            return self._pair_forward_general(input_)
+        grad = torch.is_grad_enabled()
+        need_w, need_x = grad and weight.requires_grad, grad and input_.requires_grad
+        ac = pp[0] != 0 and torch.is_autocast_enabled("cuda")      # (code 0: fp32 tensors are untouched by autocast)
+        if ac and torch.get_autocast_dtype("cuda") is not weight.dtype:
+            return self._pair_forward_general(input_)
+        share = _SHARE_ACT and _top_hooks is not None
+        if share:
+            st = _state()
+            key = (_SymQuantizerOperand, self.a_bits, False, _MODE_CODE["mask"] + 4 * ops._semantics + (8 if grad else 0) + (16 if ac else 0))
+            region, stream = _region(), ops._raw_stream(pp[6])
+            raw = _act_lookup(st, key, input_, region, stream)
+            if raw is not None:
+                # a sibling projection already quantized this activation: only the weight is left to do.  One node over both where the
+                # remembered data has the pair's shape (mask mode, operand dtype); otherwise the two ordinary nodes
+                if raw.mode not in ("mask", "none") or raw.out.dtype is not weight.dtype:
+                    return None
+                res = ops.weight_forward(weight, self.w_bits, -2.0, 2.0, need_w)
+                if res is None:
+                    return None
+                _count("act_share_hit")
+                _count("single_launch")
+                wq, side_w, rows_w, cols = res
+                if not (need_w or need_x):
+                    return wq, raw.out
+                return _PairNode.apply(weight, input_, (wq, raw.out, side_w, raw.saved[0] if need_x else None, rows_w, pp[3], cols), pp[0], True)
+        elif _SHARE_ACT:
+            _memory_ok("share")   # counts / warns: the region API is missing, nothing is remembered
+        res = ops.pair_forward_planned(weight, input_, pp, self.w_bits, self.a_bits, need_w, need_x, ac)
+        if res is None:
+            return self._pair_forward_general(input_)
+        _count("pair_launch")
+        out = _PairNode.apply(weight, input_, res, pp[0], False) if (need_w or need_x) else (res[0], res[1])
+        if share:
+            # remembered for the sibling projections: the data (for a sibling's view of it: _PairNode / _SharedAct) + its side buffer.
+            # out[1] is this node's own output tensor when there is a node; siblings never use it as a tensor of their graph.
+            _count("act_share_miss")
+            st.acts[key] = (weakref.ref(input_), input_._version, input_.data_ptr(), _Raw(out[1], "mask", (res[3],), (-2.0, 2.0), (pp[3], pp[1])) if need_x
+                            else _Raw(out[1], "none"), out[1]._version, input_.requires_grad, region, stream)
+        return out
+
+    def _pair_forward_general(self, input_):
+        """the same decision without a plan: strided operands, the weight cache, inference tensors, dtype mixes (ops.pair_forward's checks)"""
+        if not (3 <= self.w_bits < 32 and 2 < self.a_bits < 32):
             return None
         weight = self.weight
         if input_.is_inference() or weight.is_inference():
@@ -1036,26 +1096,13 @@ class QuantizeLinear(nn.Linear):
             st = _state()
             key = (_SymQuantizerOperand, self.a_bits, False, _state_word(input_))
             region, stream = _region(), (ops._stream(input_) if input_.is_cuda else 0)
-            raw = _act_lookup(st, key, input_, region, stream)
-            if raw is not None:
-                # a sibling projection already quantized this activation: only the weight is left to do.  One node over both where the
-                # remembered data has the pair's shape (mask mode, operand dtype); otherwise the two ordinary nodes
-                if wkey is not None or raw.mode not in ("mask", "none") or raw.out.dtype != weight.dtype:
-                    return None
-                res = ops.weight_forward(weight, self.w_bits, -2.0, 2.0, need_w)
-                if res is None:
-                    return None
-                _count("act_share_hit")
-                _count("single_launch")
-                wq, side_w, rows_w, cols = res
-                if not (need_w or need_x):
-                    return wq, raw.out
-                rows_x = raw.rows_cols[0] if raw.rows_cols else 0
-                return _PairNode.apply(weight, input_, (wq, raw.out, side_w, raw.saved[0] if need_x else None, rows_w, rows_x, cols), (-2.0, 2.0), True, True)
+            if _act_lookup(st, key, input_, region, stream) is not None:
+                return None   # a sibling already quantized this activation: the weight's own node + a _SharedAct over the remembered data
         res = ops.pair_forward(weight, input_, self.w_bits, self.a_bits, -2.0, 2.0, need_w or wkey is not None, need_x)
         if res is None:
             return None
         _count("pair_launch")
+        code = ops._DTYPES[weight.dtype]
         if share:
             _count("act_share_miss")
             rows_x, cols = res[5], res[6]
@@ -1073,7 +1120,7 @@ class QuantizeLinear(nn.Linear):
             xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if need_x else res[1]
             return wq, xq
         if need_w or need_x:
-            return _PairNode.apply(weight, input_, res, (-2.0, 2.0), True, share)
+            return _PairNode.apply(weight, input_, res, code, share)
         return res[0], res[1]
 
     def export_weight(self, container=None):

@@ -18,11 +18,11 @@ namespace fq {
 // the vector slots instead of 10 %, 576 x 3 for 13824, 320 x 2 for 5120 -- and with 256 x 6 for mid-sized tensors: within +-2 % of
 // the shapes below everywhere, profiles/r03_kbench_block_shapes.txt, r03_ab_mid_rows_256.txt) (11008 bf16 cols: 512 thr x 3 = 30.6 us, 256 x 6 = 31.1, 1024 x 2 = 32.2;
 // 4096 cols: 256 x 2 = 6.1 us, 128 x 4 = 6.3, 64 x 8 = 6.9, 512 x 1 = 7.7).
-template <int DT, bool ASYM, bool FAST, bool NTL, bool NTS, bool DBG>
+template <int DT, bool ASYM, bool FAST, bool NTL, bool NTS, bool DBG, bool PITCH = false>
 static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #define R(TPR, V)                                                                                                   \
     case V:                                                                                                         \
-        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NTL, NTS, DBG>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows), \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, ASYM, FAST, NTL, NTS, DBG, 0, PITCH>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows), \
                   (TPR == 64 ? 256 : TPR), st, a);                                                                  \
         break;
     if (nvec <= 192) {
@@ -39,11 +39,11 @@ static void launch_reg(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #undef R
 }
 
-template <int DT, int AC, bool NTL, bool NTS>
+template <int DT, int AC, bool NTL, bool NTS, bool PITCH = false>
 static void launch_reg_ac(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #define R(TPR, V)                                                                                                            \
     case V:                                                                                                                  \
-        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, false, false, NTL, NTS, false, AC>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),  \
+        FQ_LAUNCH((row_reg_kernel<DT, TPR, V, false, false, NTL, NTS, false, AC, PITCH>), (TPR == 64 ? (a.rows + 3) / 4 : a.rows),  \
                   (TPR == 64 ? 256 : TPR), st, a);                                                                           \
         break;
     if (nvec <= 192) {
@@ -60,16 +60,16 @@ static void launch_reg_ac(const RowArgs& a, int64_t nvec, hipStream_t st) {
 #undef R
 }
 
-template <int DT, int TPR, bool NTL, bool NTS>
+template <int DT, int TPR, bool NTL, bool NTS, bool PITCH = false>
 static void launch_wide(const RowArgs& a, int hpt, hipStream_t st) {
     const int64_t grid = TPR == 64 ? (a.rows + 3) / 4 : a.rows;
     constexpr int BLOCK = TPR == 64 ? 256 : TPR;
-    const bool mask = any_mask(a);  // the mask-recording code lives in its own instantiation (it costs the plain one 7 %)
+    const bool mask = any_mask(a) || PITCH;  // the mask-recording code lives in its own instantiation (it costs the plain one 7 %); pitched rows: one flavour
     switch (hpt) {
 #define H(N)                                                                                            \
     case N:                                                                                             \
-        if (mask) FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, true>), grid, BLOCK, st, a);     \
-        else FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, false>), grid, BLOCK, st, a);         \
+        if (mask) FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, true, PITCH>), grid, BLOCK, st, a);     \
+        else if constexpr (!PITCH) FQ_LAUNCH((row_reg_wide_kernel<DT, TPR, N, NTL, NTS, false>), grid, BLOCK, st, a);         \
         break;
         H(1) H(2) H(3) H(4) H(5) H(6) case 7: H(8)
 #undef H
@@ -103,7 +103,8 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
 #define W(TPR)                                                                                          \
     {                                                                                                   \
         const int hpt = (int)((nh + TPR - 1) / TPR);                                                    \
-        if (ntl) launch_wide<DT, TPR, true, true>(a, hpt, st);                                          \
+        if (pitched) launch_wide<DT, TPR, false, true, true>(a, hpt, st);                               \
+        else if (ntl) launch_wide<DT, TPR, true, true>(a, hpt, st);                                     \
         else launch_wide<DT, TPR, false, true>(a, hpt, st);                                             \
     }
                 if (nh <= 512) W(64) else if (nh <= 2048) W(256) else W(1024)
@@ -124,7 +125,8 @@ static int sym_autocast_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         }
         if (AC == 1 && vec_ok && nvec <= REG_MAX_VEC) {
             if constexpr (AC == 1) {
-                if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
+                if (pitched) launch_reg_ac<DT, AC, false, true, true>(a, nvec, st);   // rows that do not follow one another: their own instantiations
+                else if (bytes >= NT_LOAD_MIN_BYTES) launch_reg_ac<DT, AC, true, true>(a, nvec, st);
                 else launch_reg_ac<DT, AC, false, true>(a, nvec, st);
             }
         } else if (a.mask) {
@@ -174,6 +176,7 @@ static int rowwise_t(RowArgs a, void* ws, size_t wsb, hipStream_t st) {
         // the diagnostic outputs (bin indices, scales) live in their own instantiation so the product
         // kernels carry none of that code; it runs the same arithmetic with the default cache policy
         if (a.idx || a.scale) launch_reg<DT, ASYM, FAST, false, false, true>(a, nvec, st);
+        else if (pitched) launch_reg<DT, ASYM, FAST, false, true, false, true>(a, nvec, st);   // rows that do not follow one another: their own instantiations
         else if (ntl) launch_reg<DT, ASYM, FAST, true, true, false>(a, nvec, st);
         else launch_reg<DT, ASYM, FAST, false, true, false>(a, nvec, st);
     } else if (a.mask) {
@@ -263,7 +266,8 @@ int launch_ste_rows(const void* g, const void* x, void* gx, int64_t rows, int64_
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
 #define S(V)                                                                                                                              \
     case V:                                                                                                                               \
-        if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);        \
+        if (pitched) FQ_LAUNCH((ste_rows_kernel<DT, V, false, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);  \
+        else if (ntl) FQ_LAUNCH((ste_rows_kernel<DT, V, true, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);        \
         else FQ_LAUNCH((ste_rows_kernel<DT, V, false, true>), rows * chunks, STE_THREADS, st, g, x, gx, nvec_row, chunks, cv, bounds, lo, hi, pitch);           \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
@@ -311,9 +315,12 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
         if (!L.t[i].inplace && L.t[i].rows > big_rows) big_rows = L.t[i].rows;
     const int64_t bytes = big_rows * cols * T::ESIZE;
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
+    bool pitched = false;
+    for (int i = 0; i < L.n; ++i) pitched = pitched || L.t[i].gp.on || L.t[i].op.on;
 #define S(V)                                                                                                               \
     case V:                                                                                                                \
-        if (ntl) FQ_LAUNCH2((ste_mask_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);        \
+        if (pitched) FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);   \
+        else if (ntl) FQ_LAUNCH2((ste_mask_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);        \
         else FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);           \
         break;
     switch (vpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }
@@ -342,9 +349,12 @@ template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, 
         if (grid > 0x7FFFFFFF) return fail(FQ_ERR_SHAPE, "rows exceed the grid limit");
         const int64_t bytes = largest_rows(L) * cols * 4;  // the fp32 gradient is the larger stream
         const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
+        bool pitched = false;
+        for (int i = 0; i < L.n; ++i) pitched = pitched || L.t[i].gp.on || L.t[i].op.on;
 #define S(V)                                                                                                                  \
     case V:                                                                                                                   \
-        if (ntl) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);        \
+        if (pitched) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);   \
+        else if (ntl) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);        \
         else FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);           \
         break;
         switch (hpt) { S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) }

@@ -31,13 +31,17 @@ struct RowPitch {
     uint32_t n_inner;
     uint32_t on;
 };
-__device__ __forceinline__ int64_t row_byte_off(int64_t row, int64_t row_bytes, const RowPitch& p) {
-#ifdef FQ_AB_NO_PITCH   // A/B build only (tools/ab_bench.sh): the address arithmetic of rounds 1-4, to price the pitch branch
-    return row * row_bytes;
-#endif
-    if (!p.on) return row * row_bytes;
-    const uint32_t r = (uint32_t)row, q = r / p.n_inner;
-    return (int64_t)q * p.outer + (int64_t)(r - q * p.n_inner) * p.inner;
+// PITCH is a template parameter of the streaming kernels: as a run-time (block-uniform) branch the pitch cost the contiguous launches
+// 3-7 % at [2048,4096] and 0.4-1.6 % at [4096,11008] (the extra kernarg loads and scalar selects sit in every block's prologue:
+// profiles/r05_ab_pitch_branch.txt), so contiguous tensors run the instantiations they always ran and pitched ones their own.
+template <bool PITCH = true> __device__ __forceinline__ int64_t row_byte_off(int64_t row, int64_t row_bytes, const RowPitch& p) {
+    if constexpr (!PITCH) {
+        return row * row_bytes;
+    } else {
+        if (!p.on) return row * row_bytes;
+        const uint32_t r = (uint32_t)row, q = r / p.n_inner;
+        return (int64_t)q * p.outer + (int64_t)(r - q * p.n_inner) * p.inner;
+    }
 }
 
 struct TensorSlot {
@@ -170,7 +174,7 @@ template <int DT> __device__ __forceinline__ uint4 ste_mask_apply(const uint4& g
 //   Out-of-range slots re-load the row's last vector (idempotent for max/min), so no load
 //   sits behind a branch; only stores are predicated.
 // ------------------------------------------------------------------------------------
-template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false, int AC = 0>
+template <int DT, int TPR, int VPT, bool ASYM, bool FAST, bool NTL = true, bool NTS = true, bool DBG = false, int AC = 0, bool PITCH = false>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs a) {
     using T = Ty<DT>;
     static_assert(AC == 0 || (AC == 1 && !ASYM && !DBG && T::ESIZE == 2), "autocast arithmetic: Sym on 16-bit tensors");
@@ -214,15 +218,17 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_kernel(RowArgs 
                 bnd = a.more[i].bounds;
                 msk = a.more[i].mask;
                 symk.qmax = a.more[i].qmax;
-                xp = a.more[i].xp;
-                yp = a.more[i].yp;
+                if constexpr (PITCH) {
+                    xp = a.more[i].xp;
+                    yp = a.more[i].yp;
+                }
             }
         }
         row -= rbase;
     }
     const int nvec = (int)(a.cols / EPV);
-    const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row_byte_off(row, a.cols * T::ESIZE, xp));
-    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off(row, a.cols * T::ESIZE, yp));
+    const uint4* __restrict__ xr = (const uint4*)((const char*)xb + row_byte_off<PITCH>(row, a.cols * T::ESIZE, xp));
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off<PITCH>(row, a.cols * T::ESIZE, yp));
 
     uint4 r[VPT];
 #pragma unroll
@@ -416,7 +422,7 @@ template <bool NT> __device__ __forceinline__ void st8(uint2* p, uint2 v) {
     }
 }
 
-template <int DT, int TPR, int HPT, bool NTL, bool NTS, bool MASK>
+template <int DT, int TPR, int HPT, bool NTL, bool NTS, bool MASK, bool PITCH = false>
 __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(RowArgs a) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "16-bit input, fp32 output");
@@ -449,15 +455,17 @@ __global__ __launch_bounds__(TPR == 64 ? 256 : TPR) void row_reg_wide_kernel(Row
                 bnd = a.more[i].bounds;
                 msk = a.more[i].mask;
                 qmax = a.more[i].qmax;
-                xp = a.more[i].xp;
-                yp = a.more[i].yp;
+                if constexpr (PITCH) {
+                    xp = a.more[i].xp;
+                    yp = a.more[i].yp;
+                }
             }
         }
         row -= rbase;
     }
     const int nh = (int)(a.cols / 4);
-    const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row_byte_off(row, a.cols * 2, xp));
-    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off(row, a.cols * 4, yp));
+    const uint2* __restrict__ xr = (const uint2*)((const char*)xb + row_byte_off<PITCH>(row, a.cols * 2, xp));
+    uint4* __restrict__ yr = (uint4*)((char*)yb + row_byte_off<PITCH>(row, a.cols * 4, yp));
     uint2 r[HPT];
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
@@ -858,15 +866,15 @@ __global__ __launch_bounds__(STE_THREADS) void ste_scalar_kernel(const void* __r
 struct StePitch3 {
     RowPitch g, x, o;   // of grad_output, the forward's input and the result (RowPitch above)
 };
-template <int DT, int VPT, bool NTL = true, bool NTS = true>
+template <int DT, int VPT, bool NTL = true, bool NTS = true, bool PITCH = false>
 __global__ __launch_bounds__(STE_THREADS) void ste_rows_kernel(const void* __restrict__ g, const void* __restrict__ x,
                                                                void* __restrict__ gx, int64_t nvec_row, int64_t chunks, int cv,
                                                                const float* __restrict__ bounds, float lo, float hi, StePitch3 p) {
     const int64_t row = blockIdx.x / chunks;
     const int64_t vs = (blockIdx.x % chunks) * cv;
-    const uint4* gr = (const uint4*)((const char*)g + row_byte_off(row, nvec_row * 16, p.g)) + vs;
-    const uint4* xr = (const uint4*)((const char*)x + row_byte_off(row, nvec_row * 16, p.x)) + vs;
-    uint4* or_ = (uint4*)((char*)gx + row_byte_off(row, nvec_row * 16, p.o)) + vs;
+    const uint4* gr = (const uint4*)((const char*)g + row_byte_off<PITCH>(row, nvec_row * 16, p.g)) + vs;
+    const uint4* xr = (const uint4*)((const char*)x + row_byte_off<PITCH>(row, nvec_row * 16, p.x)) + vs;
+    uint4* or_ = (uint4*)((char*)gx + row_byte_off<PITCH>(row, nvec_row * 16, p.o)) + vs;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
     bool safe = false;   // no recorded bounds (pitched tensors in the plain data flow): every row re-reads x
@@ -1121,7 +1129,7 @@ template <int EPL, int SLOTS> struct SteMaskHeld {
 // which tensor of the launch a block belongs to.  Branch-free on purpose: every kernarg field is loaded up front and chosen
 // with scalar selects (a chain of `if (blockIdx >= begin_i) slot = t[i]` compiled to three dependent s_load / s_waitcnt /
 // s_cbranch round trips in the prologue of every block).  Unused slots carry blk_begin = INT64_MAX (host).
-__device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) {
+template <bool PITCH = false> __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) {
     static_assert(MAX_MORE == 3, "four slots");
     const int64_t b1 = L.t[1].blk_begin, b2 = L.t[2].blk_begin, b3 = L.t[3].blk_begin;
     const int s = (int)(b >= b1) + (int)(b >= b2) + (int)(b >= b3);
@@ -1134,21 +1142,25 @@ __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) 
     FQ_PICK(rows);
     FQ_PICK(blk_begin);
     FQ_PICK(inplace);
-    FQ_PICK(gp);
-    FQ_PICK(op);
+    if constexpr (PITCH) {
+        FQ_PICK(gp);
+        FQ_PICK(op);
+    } else {
+        r.gp = r.op = RowPitch{};
+    }
 #undef FQ_PICK
     return r;
 }
 
 // one chunk (cv vectors from vector vs) of one row.  `bounds` non-null: the row's {upper, lower} bounds are read HERE, after
 // the gradient and mask loads have been issued, so that nothing waits on them (null: the caller knows the row can clip).
-template <int DT, int VPT, bool NTL, bool NTS>
+template <int DT, int VPT, bool NTL, bool NTS, bool PITCH = false>
 __device__ __forceinline__ void ste_mask_chunk(const void* g, void* gx, const uint8_t* mrow, int mrow_dwords, int64_t row, int64_t nvec_row,
                                                int64_t vs, int cv, const float* bounds, float lo, float hi, int t, const RowPitch& gp,
                                                const RowPitch& op) {
     using T = Ty<DT>;
-    const uint4* gr = (const uint4*)((const char*)g + row_byte_off(row, nvec_row * 16, gp)) + vs;
-    uint4* or_ = (uint4*)((char*)gx + row_byte_off(row, nvec_row * 16, op)) + vs;
+    const uint4* gr = (const uint4*)((const char*)g + row_byte_off<PITCH>(row, nvec_row * 16, gp)) + vs;
+    uint4* or_ = (uint4*)((char*)gx + row_byte_off<PITCH>(row, nvec_row * 16, op)) + vs;
     const int64_t rem = nvec_row - vs;
     const int nvec = (int)(rem < cv ? rem : cv);
     uint4 rg[VPT];
@@ -1184,14 +1196,14 @@ __device__ __forceinline__ void ste_mask_chunk(const void* g, void* gx, const ui
 }
 
 // grid: x = the slots' row blocks (a copying slot: one per row; an in-place slot: one per STE_THREADS rows), y = chunk of the row
-template <int DT, int VPT, bool NTL = true, bool NTS = true>
+template <int DT, int VPT, bool NTL = true, bool NTS = true, bool PITCH = false>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int64_t nvec_row, int cv, int64_t mask_row_words, float lo, float hi) {
     __shared__ uint64_t unsafe_rows[STE_THREADS / 64];
     const int t = threadIdx.x;
-    const SteSlot sl = ste_pick_slot(L, (int64_t)blockIdx.x);
+    const SteSlot sl = ste_pick_slot<PITCH>(L, (int64_t)blockIdx.x);
     const int64_t local = (int64_t)blockIdx.x - sl.blk_begin;
     if (!sl.inplace) {
-        ste_mask_chunk<DT, VPT, NTL, NTS>(sl.g, sl.gx, (const uint8_t*)(sl.mask + local * mask_row_words), (int)mask_row_words * 2, local, nvec_row,
+        ste_mask_chunk<DT, VPT, NTL, NTS, PITCH>(sl.g, sl.gx, (const uint8_t*)(sl.mask + local * mask_row_words), (int)mask_row_words * 2, local, nvec_row,
                                           (int64_t)blockIdx.y * cv, cv, sl.bounds, lo, hi, t, sl.gp, sl.op);
         return;
     }
@@ -1215,7 +1227,7 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int6
             const uint8_t* mrow = (const uint8_t*)(sl.mask + row * mask_row_words);
 #pragma unroll 1
             for (int c = 0; c < (int)gridDim.y; ++c)
-                ste_mask_chunk<DT, VPT, false, false>(sl.g, sl.gx, mrow, (int)mask_row_words * 2, row, nvec_row, (int64_t)c * cv, cv, nullptr, lo, hi, t,
+                ste_mask_chunk<DT, VPT, false, false, PITCH>(sl.g, sl.gx, mrow, (int)mask_row_words * 2, row, nvec_row, (int64_t)c * cv, cv, nullptr, lo, hi, t,
                                                       sl.gp, sl.op);
         }
     }
@@ -1226,16 +1238,16 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int6
 // (read 4 B + write 2 B per element instead of a cast kernel followed by a 16-bit STE kernel).  A lane owns 4 elements
 // (one 16-byte fp32 vector in, one 8-byte 16-bit half-vector out) = one nibble of the row bitmap.  ch is a multiple of 64.
 // grid: x = rows of all slots, y = chunk of the row.
-template <int DT, int HPT, bool NTL = true, bool NTS = true>
+template <int DT, int HPT, bool NTL = true, bool NTS = true, bool PITCH = false>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(SteLaunch L, int64_t nh_row, int ch, int64_t mask_row_words, float lo, float hi) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "fp32 gradient in, 16-bit gradient out");
     typedef short s16x2_t __attribute__((ext_vector_type(2)));
-    const SteSlot sl = ste_pick_slot(L, (int64_t)blockIdx.x);
+    const SteSlot sl = ste_pick_slot<PITCH>(L, (int64_t)blockIdx.x);
     const int64_t row = (int64_t)blockIdx.x - sl.blk_begin;
     const int64_t hs = (int64_t)blockIdx.y * ch;
-    const uint4* gr = (const uint4*)((const char*)sl.g + row_byte_off(row, nh_row * 16, sl.gp)) + hs;   // fp32 gradient: 16 bytes per lane
-    uint2* or_ = (uint2*)((char*)sl.gx + row_byte_off(row, nh_row * 8, sl.op)) + hs;                    // 16-bit result: 8 bytes per lane
+    const uint4* gr = (const uint4*)((const char*)sl.g + row_byte_off<PITCH>(row, nh_row * 16, sl.gp)) + hs;   // fp32 gradient: 16 bytes per lane
+    uint2* or_ = (uint2*)((char*)sl.gx + row_byte_off<PITCH>(row, nh_row * 8, sl.op)) + hs;                    // 16-bit result: 8 bytes per lane
     const int64_t rem = nh_row - hs;
     const int nh = (int)(rem < ch ? rem : ch);
     const int t = threadIdx.x;

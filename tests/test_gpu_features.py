@@ -170,8 +170,13 @@ def test_low_bit_fused_row_mean(pkg):
 
 
 class Counter:
+    """counts calls of the named `ops` functions; pair_forward / pair_backward stand for their lean twins of the module's hot path too
+    (ops.pair_forward_planned / pair_backward_planned: same launches)"""
+    TWINS = {"pair_forward": "pair_forward_planned", "pair_backward": "pair_backward_planned"}
+
     def __init__(self, mod, names):
-        self.mod, self.names, self.n = mod, names, 0
+        self.mod, self.n = mod, 0
+        self.names = list(names) + [self.TWINS[n] for n in names if n in self.TWINS and hasattr(mod, self.TWINS[n])]
 
     def __enter__(self):
         self.orig = {n: getattr(self.mod, n) for n in self.names}
@@ -1206,11 +1211,15 @@ def test_inplace_weight_gradient_is_guarded(pkg):
     x = (torch.randn(16, 512, device="cuda") * 1.2).bfloat16().requires_grad_(True)
 
     flags = []
-    orig_pb = U.ops.pair_backward
+    orig_pb, orig_pbp = U.ops.pair_backward, U.ops.pair_backward_planned
 
     def pb_spy(*a, inplace_w=False, **k):
         flags.append(bool(inplace_w))
         return orig_pb(*a, inplace_w=inplace_w, **k)
+
+    def pbp_spy(*a):                      # the module's lean twin: inplace_w is its last positional argument
+        flags.append(bool(a[-1]))
+        return orig_pbp(*a)
 
     def grads(hook=None):
         lin.weight.grad = x.grad = None
@@ -1224,13 +1233,13 @@ def test_inplace_weight_gradient_is_guarded(pkg):
                 w.register_hook(lambda g: seen.__setitem__("g", g))      # keeps the very tensor the node is about to receive
             return orig(inp, w, b)
         torch.nn.functional.linear = spy
-        U.ops.pair_backward = pb_spy
+        U.ops.pair_backward, U.ops.pair_backward_planned = pb_spy, pbp_spy
         try:
             y = lin(x)
             y.float().square().sum().backward()
         finally:
             torch.nn.functional.linear = orig
-            U.ops.pair_backward = orig_pb
+            U.ops.pair_backward, U.ops.pair_backward_planned = orig_pb, orig_pbp
         return lin.weight.grad.clone(), x.grad.clone(), seen.get("g")
 
     pkg.inplace_weight_grad(False)

@@ -26,7 +26,7 @@ DIMS = {"7b": dict(hidden_size=4096, intermediate_size=11008, num_attention_head
         "13b": dict(hidden_size=5120, intermediate_size=13824, num_attention_heads=40)}
 LAUNCHING = ("fq_sym_fwd", "fq_asym_fwd", "fq_sym_fwd_train", "fq_asym_fwd_train", "fq_sym_fwd_autocast", "fq_sym_fwd_pair", "fq_sym_fwd_multi",
              "fq_ste_bwd", "fq_ste_bwd_rows", "fq_ste_bwd_mask", "fq_ste_bwd_mask_pair", "fq_ste_bwd_mask_multi", "fq_ste_bwd_mask_wide", "fq_w12_fwd",
-             "fq_w12_fwd_rows")
+             "fq_w12_fwd_rows", "fq_rowwise_fwd_v", "fq_sym_fwd_multi_v", "fq_ste_bwd_mask_multi_v", "fq_ste_bwd_v")
 
 
 class LaunchCounter:

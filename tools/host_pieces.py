@@ -97,7 +97,7 @@ res["raw ctypes fq_sym_fwd_pair (21 prebuilt args)"] = timeit(lambda: fn(*args))
 res["4 allocations (2 empty_like 90 MB + 2 side buffers)"] = timeit(lambda: (torch.empty_like(w), torch.empty_like(a), torch.empty(rows * 8 + mw, dtype=torch.uint8, device=dev),
                                                                              torch.empty(rows * 8 + mx, dtype=torch.uint8, device=dev)))
 res["8 data_ptr() calls"] = timeit(lambda: (w.data_ptr(), a.data_ptr(), wq.data_ptr(), xq.data_ptr(), sw.data_ptr(), sx.data_ptr(), w.data_ptr(), a.data_ptr()))
-res["_PairNode.apply on a prebuilt result"] = timeit(lambda: UQ._PairNode.apply(w, a, r, (-2.0, 2.0), True, True))
+res["_PairNode.apply on a prebuilt result"] = timeit(lambda: UQ._PairNode.apply(w, a, r, _lib.DTYPE_BF16, False))
 res["_NoGemm.apply (the stand-in's own Function)"] = timeit(lambda: _NoGemm.apply(a, w))
 res["nn.Module.__call__ of an empty module"] = timeit(lambda m=torch.nn.Identity(): m(a))
 res["_state_word + _region + _stream + key tuple"] = timeit(lambda: (UQ._state_word(a), UQ._region(), ops._stream(a), (UQ._SymQuantizerOperand, 8, False, 3)))
@@ -130,6 +130,7 @@ def timed(name, f):
 
 UQ._PairNode.backward = staticmethod(timed("node", orig_node))
 ops.pair_backward = timed("pair_backward", orig_pb)
+ops.pair_backward_planned = timed("pair_backward", ops.pair_backward_planned)
 _NoGemm.backward = staticmethod(timed("nogemm", orig_ng))
 tot = 0.0
 M = 320

@@ -119,6 +119,34 @@ def test_gpus_4_stub_counts_every_rank():
     assert out["n_gpus"] == 4 and out["ranks_seen"] == 4
 
 
+def test_gpus_8_stub_is_the_drivers_config_5_command_end_to_end():
+    """BASELINE configs[4] (LLaMA-13B, 8 x MI355X, outer DDP loop only): the exact shape of the driver's command, `bench.py --gpus 8 --steps K
+    --warmup W`, rehearsed on CPU with the stub step -- eight spawned ranks, one line, every rank counted, weak scaling (replicas)"""
+    p, out = _run_bench(["--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["scaling"] == "weak" and out["data"] == "stub"
+    assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1
+    # whole-job value: eight ranks' elements over the slowest rank's time
+    assert abs(out["value"] - 1000 * 3 * 8 / (out["ms_per_step"] * 3 / 1e3) / 1e9) < 1e-9
+
+
+def test_gpus_8_under_the_launcher_command(tmp_path):
+    """the same through `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py ...`,
+    as the driver launches N > 1"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]      # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8
+
+
 def test_never_reports_fewer_ranks_than_asked():
     # a launcher that started the wrong number of ranks: refuse, print no JSON line
     p, out = _run_bench(["--gpus", "2", "--stub", "--steps", "2", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0"}, drop=())

@@ -317,6 +317,27 @@ template <int DT> int launch_ste_mask(SteLaunch L, int64_t cols, float lo, float
     const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
     bool pitched = false;
     for (int i = 0; i < L.n; ++i) pitched = pitched || L.t[i].gp.on || L.t[i].op.on;
+    if (L.n == 1 && !L.t[0].inplace && !pitched) {   // one copying tensor: its own lean kernel (fq_kernels.h, ste_mask_one_kernel)
+        const SteSlot& t0 = L.t[0];
+#define S1(V)                                                                                                                                            \
+    case V:                                                                                                                                              \
+        if (ntl) FQ_LAUNCH2((ste_mask_one_kernel<DT, V, true, true>), grid, chunks, STE_THREADS, st, t0.g, t0.gx, t0.bounds, t0.mask, nvec_row, cv, mrw, lo, hi);   \
+        else FQ_LAUNCH2((ste_mask_one_kernel<DT, V, false, true>), grid, chunks, STE_THREADS, st, t0.g, t0.gx, t0.bounds, t0.mask, nvec_row, cv, mrw, lo, hi);      \
+        break;
+        switch (vpt) { S1(1) S1(2) S1(3) S1(4) S1(5) S1(6) S1(7) S1(8) }
+#undef S1
+        return launch_result();
+    }
+    if (L.n <= 2 && !pitched) {   // two tensors (a QuantizeLinear's weight + input): the slot pick looks at two slots instead of four
+#define S2(V)                                                                                                                  \
+    case V:                                                                                                                    \
+        if (ntl) FQ_LAUNCH2((ste_mask_kernel<DT, V, true, true, false, 2>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);   \
+        else FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true, false, 2>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);      \
+        break;
+        switch (vpt) { S2(1) S2(2) S2(3) S2(4) S2(5) S2(6) S2(7) S2(8) }
+#undef S2
+        return launch_result();
+    }
 #define S(V)                                                                                                               \
     case V:                                                                                                                \
         if (pitched) FQ_LAUNCH2((ste_mask_kernel<DT, V, false, true, true>), grid, chunks, STE_THREADS, st, L, nvec_row, cv, mrw, lo, hi);   \
@@ -351,6 +372,16 @@ template <int DT> int launch_ste_mask_wide(SteLaunch L, int64_t cols, float lo, 
         const bool ntl = bytes >= NT_LOAD_MIN_BYTES;
         bool pitched = false;
         for (int i = 0; i < L.n; ++i) pitched = pitched || L.t[i].gp.on || L.t[i].op.on;
+        if (!ntl && !pitched && L.n <= 2) {   // the K / V-sized launches: one or two slots instead of a four-slot pick in every block's prologue
+#define SN(V)                                                                                                                                  \
+    case V:                                                                                                                                    \
+        if (L.n == 1) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true, false, 1>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);        \
+        else FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true, false, 2>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);                 \
+        break;
+            switch (hpt) { SN(1) SN(2) SN(3) SN(4) SN(5) SN(6) SN(7) SN(8) }
+#undef SN
+            return launch_result();
+        }
 #define S(V)                                                                                                                  \
     case V:                                                                                                                   \
         if (pitched) FQ_LAUNCH2((ste_mask_wide_kernel<DT, V, false, true, true>), grid, chunks, STE_THREADS, st, L, nh_row, ch, mrw, lo, hi);   \

@@ -1129,11 +1129,32 @@ template <int EPL, int SLOTS> struct SteMaskHeld {
 // which tensor of the launch a block belongs to.  Branch-free on purpose: every kernarg field is loaded up front and chosen
 // with scalar selects (a chain of `if (blockIdx >= begin_i) slot = t[i]` compiled to three dependent s_load / s_waitcnt /
 // s_cbranch round trips in the prologue of every block).  Unused slots carry blk_begin = INT64_MAX (host).
-template <bool PITCH = false> __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) {
-    static_assert(MAX_MORE == 3, "four slots");
+// NS: how many slots the launch can have (4, or 2: a QuantizeLinear's weight + input, K + V -- the launch then loads and selects among
+// half the kernarg fields; a one-tensor copying launch has a kernel of its own, ste_mask_one_kernel).
+template <bool PITCH = false, int NS = 4> __device__ __forceinline__ SteSlot ste_pick_slot(const SteLaunch& L, int64_t b) {
+    static_assert(MAX_MORE == 3 && (NS == 2 || NS == 4), "four slots, or the first two");
+    SteSlot r;
+    if constexpr (NS == 2) {
+        const bool s1 = b >= L.t[1].blk_begin;
+#define FQ_PICK2(f) r.f = s1 ? L.t[1].f : L.t[0].f
+        FQ_PICK2(g);
+        FQ_PICK2(gx);
+        FQ_PICK2(bounds);
+        FQ_PICK2(mask);
+        FQ_PICK2(rows);
+        FQ_PICK2(blk_begin);
+        FQ_PICK2(inplace);
+        if constexpr (PITCH) {
+            FQ_PICK2(gp);
+            FQ_PICK2(op);
+        } else {
+            r.gp = r.op = RowPitch{};
+        }
+#undef FQ_PICK2
+        return r;
+    }
     const int64_t b1 = L.t[1].blk_begin, b2 = L.t[2].blk_begin, b3 = L.t[3].blk_begin;
     const int s = (int)(b >= b1) + (int)(b >= b2) + (int)(b >= b3);
-    SteSlot r;
 #define FQ_PICK(f) r.f = s == 0 ? L.t[0].f : s == 1 ? L.t[1].f : s == 2 ? L.t[2].f : L.t[3].f
     FQ_PICK(g);
     FQ_PICK(gx);
@@ -1196,11 +1217,23 @@ __device__ __forceinline__ void ste_mask_chunk(const void* g, void* gx, const ui
 }
 
 // grid: x = the slots' row blocks (a copying slot: one per row; an in-place slot: one per STE_THREADS rows), y = chunk of the row
-template <int DT, int VPT, bool NTL = true, bool NTS = true, bool PITCH = false>
+// ONE copying tensor per launch, nothing else (round 5): the gradient of an activation, of K, of V -- [2048,4096]-sized launches that are
+// mostly launch boundary.  Without the slot table (four slots' kernarg fields loaded and selected in every block's prologue), the
+// in-place path and its LDS the same chunk body runs 10-11 % faster there (6.97 -> 6.23 us; tools/small_rows_2perwg.hip, which also shows
+// that putting two or four rows into one workgroup adds nothing on top: profiles/r05_ab_small_rows_2perwg.txt).
+template <int DT, int VPT, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__(STE_THREADS) void ste_mask_one_kernel(const void* g, void* gx, const float* bounds, const uint64_t* mask, int64_t nvec_row, int cv,
+                                                                   int64_t mask_row_words, float lo, float hi) {
+    const int64_t row = blockIdx.x;
+    ste_mask_chunk<DT, VPT, NTL, NTS, false>(g, gx, (const uint8_t*)(mask + row * mask_row_words), (int)mask_row_words * 2, row, nvec_row, (int64_t)blockIdx.y * cv, cv,
+                                             bounds, lo, hi, (int)threadIdx.x, RowPitch{}, RowPitch{});
+}
+
+template <int DT, int VPT, bool NTL = true, bool NTS = true, bool PITCH = false, int NS = 4>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int64_t nvec_row, int cv, int64_t mask_row_words, float lo, float hi) {
     __shared__ uint64_t unsafe_rows[STE_THREADS / 64];
     const int t = threadIdx.x;
-    const SteSlot sl = ste_pick_slot<PITCH>(L, (int64_t)blockIdx.x);
+    const SteSlot sl = ste_pick_slot<PITCH, NS>(L, (int64_t)blockIdx.x);
     const int64_t local = (int64_t)blockIdx.x - sl.blk_begin;
     if (!sl.inplace) {
         ste_mask_chunk<DT, VPT, NTL, NTS, PITCH>(sl.g, sl.gx, (const uint8_t*)(sl.mask + local * mask_row_words), (int)mask_row_words * 2, local, nvec_row,
@@ -1238,12 +1271,14 @@ __global__ __launch_bounds__(STE_THREADS) void ste_mask_kernel(SteLaunch L, int6
 // (read 4 B + write 2 B per element instead of a cast kernel followed by a 16-bit STE kernel).  A lane owns 4 elements
 // (one 16-byte fp32 vector in, one 8-byte 16-bit half-vector out) = one nibble of the row bitmap.  ch is a multiple of 64.
 // grid: x = rows of all slots, y = chunk of the row.
-template <int DT, int HPT, bool NTL = true, bool NTS = true, bool PITCH = false>
+template <int DT, int HPT, bool NTL = true, bool NTS = true, bool PITCH = false, int NS = 4>
 __global__ __launch_bounds__(STE_THREADS) void ste_mask_wide_kernel(SteLaunch L, int64_t nh_row, int ch, int64_t mask_row_words, float lo, float hi) {
     using T = Ty<DT>;
     static_assert(T::ESIZE == 2, "fp32 gradient in, 16-bit gradient out");
     typedef short s16x2_t __attribute__((ext_vector_type(2)));
-    const SteSlot sl = ste_pick_slot<PITCH>(L, (int64_t)blockIdx.x);
+    SteSlot sl;   // NS = 1: K's or V's gradient alone (each has its own autograd node): the first slot as it stands, nothing to pick
+    if constexpr (NS == 1) sl = L.t[0];
+    else sl = ste_pick_slot<PITCH, NS>(L, (int64_t)blockIdx.x);
     const int64_t row = (int64_t)blockIdx.x - sl.blk_begin;
     const int64_t hs = (int64_t)blockIdx.y * ch;
     const uint4* gr = (const uint4*)((const char*)sl.g + row_byte_off<PITCH>(row, nh_row * 16, sl.gp)) + hs;   // fp32 gradient: 16 bytes per lane

@@ -522,6 +522,7 @@ def roofline_entry(name, algorithmic_bytes, timing, traffic=None, moved_bytes=No
         e["timing_method"] = method if method == "batch_mean" or pct else "batch_mean"
         if method == "bracketed_p50":
             e["us_batch_mean"] = round(batch_ms * 1e3, 2)
+            e["frac_batch_mean"] = round(moved / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)   # the round-4 way of stating the same entry
     if isinstance(timing, Timing):   # launches behind either number: `iters` after `warmup` warm-ups
         e["launches_timed"], e["warmup_launches"] = timing.iters, timing.warmup
     return e

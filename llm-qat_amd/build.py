@@ -53,7 +53,40 @@ def build_extension(force=False, verbose=False, extra_flags=(), out=None):
     return out or LIB
 
 
+# ---- the C++ autograd node (csrc/fq_autograd_node.cpp -> _fq_node.so): a PyTorch extension, host code only -------------------------------
+NODE_SRC = os.path.join(CSRC, "fq_autograd_node.cpp")
+NODE_LIB = os.path.join(HERE, "_fq_node.so")
+NODE_DEPS = [NODE_SRC, os.path.join(os.path.dirname(HERE), "include", "llmqat_fakequant.h")]
+
+
+def node_up_to_date():
+    return os.path.exists(NODE_LIB) and all(os.path.getmtime(NODE_LIB) >= os.path.getmtime(d) for d in NODE_DEPS)
+
+
+def build_node(force=False, verbose=False):
+    """g++ against the PyTorch of this interpreter (its headers, its C++ ABI flag) and the HIP runtime headers (for the current stream);
+    linked against libtorch / libc10_hip only -- the kernels are reached through function pointers of the C ABI at run time."""
+    if not force and node_up_to_date():
+        return NODE_LIB
+    import sysconfig
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_fq_node", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I" + os.path.join(tdir, "include"), "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I" + os.path.join(rocm, "include"), "-I" + sysconfig.get_paths()["include"], NODE_SRC, "-o", NODE_LIB,
+           "-L" + os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return NODE_LIB
+
+
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a[len("--out="):] for a in sys.argv[1:] if a.startswith("--out=")]
     print(build_extension(force="--force" in sys.argv, verbose=True, extra_flags=extra, out=outs[0] if outs else None))
+    if not outs:
+        print(build_node(force="--force" in sys.argv, verbose=True))

@@ -5,9 +5,9 @@ backpropagates a random loss -- and runs it twice, the drop-in under a random co
 K/V pairing, in-place weight gradients: none of which may change a result): on the live eager chain (tiny_llama.EagerQuant over
 oracle/eager_chain.py, plus the 1-/2-bit branch's op chain) and on the drop-in at default settings.
 
-What must hold for every program: the same outputs bit for bit; the same set of tensors receiving a gradient; with the shared activation
-fake-quant OFF every gradient bit for bit; with it ON every gradient equal up to the association order of bf16 sums (a documented limit of
-sharing when the shared input has further consumers: utils_quant.py point 1) -- close in a norm, never a different support.
+What must hold for every program: the same outputs bit for bit; the same set of tensors receiving a gradient; every gradient bit for bit,
+with the shared activation fake-quant off AND on (rounds 1-4 compared "up to the association order of bf16 sums" with it on; since round 5
+every sibling projection has an autograd node of its own, the reference's graph, and 2 500 programs per mode are bit-identical).
 """
 import os
 import random
@@ -22,9 +22,8 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiny_llama as TL  # noqa: E402
 
-PROGRAMS = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "60"))
+PROGRAMS = int(os.environ.get("LLMQAT_RANDOM_PROGRAMS", "300"))
 SEED0 = int(os.environ.get("LLMQAT_RANDOM_SEED0", "0"))
-STRICT_SHARE = os.environ.get("LLMQAT_RANDOM_STRICT_SHARE", "0") == "1"   # experiment: are shared-activation gradients bit-identical too?
 
 
 class EagerLowBitLinear(nn.Linear):
@@ -168,14 +167,6 @@ def eq(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num())
 
 
-def close(a, b):
-    """equal up to the association order of 16-bit sums: same NaN places, close in a norm over the finite part"""
-    if not torch.equal(a.isnan(), b.isnan()):
-        return False
-    a, b = a.float().nan_to_num(posinf=0.0, neginf=0.0), b.float().nan_to_num(posinf=0.0, neginf=0.0)
-    return float((a - b).norm()) <= 2 ** -5 * float(a.norm() + 1e-6)
-
-
 def check_program(seed, share):
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
@@ -206,10 +197,7 @@ def check_program(seed, share):
         assert (a is None) == (b is None), f"gradient {i} present in one run only, {tag}"
         if a is None:
             continue
-        if share and not cfg["conservative"] and not STRICT_SHARE:   # association order of 16-bit sums may differ where a shared input has further consumers
-            assert close(a, b), f"gradient {i} of {tag}"
-        else:
-            assert eq(a, b), f"gradient {i} of {tag}"
+        assert eq(a, b), f"gradient {i} of {tag}"   # sharing on or off (rounds 1-4: "close" with it on; since round 5 every sibling has its own node)
 
 
 @pytest.mark.parametrize("share", [False, True])

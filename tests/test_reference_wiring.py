@@ -116,8 +116,8 @@ def test_real_reference_model_on_the_dropin_cpu_path_equals_the_real_reference(w
 def test_random_programs_on_the_cpu_path_equal_the_live_reference():
     """tests/test_gpu_random_programs.py's generator (graphs of QuantizeLinear layers incl. the 1-/2-bit branches, hook-style SymQuantizer.apply
     calls, glue, no_grad regions, checkpointed steps, tensor hooks, a second backward), run on CPU tensors against the REAL reference's own
-    classes, live: the drop-in's opt-in CPU-tensor path with its host logic at random settings.  Sharing off: every output and gradient bit
-    for bit; sharing on: outputs bit for bit, gradients up to the association order of bf16 sums (utils_quant.py point 1)."""
+    classes, live: the drop-in's opt-in CPU-tensor path with its host logic at random settings.  Every output and gradient bit
+    for bit, with the shared activation fake-quant off and on (every sibling has its own autograd node: utils_quant.py point 1)."""
     import random
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
@@ -162,10 +162,7 @@ def test_random_programs_on_the_cpu_path_equal_the_live_reference():
                     assert (a is None) == (b is None), f"gradient {i} present in one run only, {tag}"
                     if a is None:
                         continue
-                    if share and not cfg["conservative"] and not RP.STRICT_SHARE:
-                        assert RP.close(a, b), f"gradient {i} of {tag}"
-                    else:
-                        assert RP.eq(a, b), f"gradient {i} of {tag}"
+                    assert RP.eq(a, b), f"gradient {i} of {tag}"
     finally:
         llm_qat_amd.allow_cpu_tensors(False)
         llm_qat_amd.reset_learned_state()

@@ -792,7 +792,9 @@ def api_path(wl, iters=60):
         return dt
 
     real = F.linear
-    F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
+    import llm_qat_amd.utils_quant as _UQ
+    no_gemm = _UQ._cnode.no_gemm_linear if _UQ._cnode is not None else _NoGemm.apply   # (the C++ stand-in: its gradients arrive without a Python wrapper, as a GEMM's do)
+    F.linear = torch.nn.functional.linear = lambda x, w, b=None: no_gemm(x, w)
     try:
         dt_floor = timed(iters, floors)
         llm_qat_amd.stats(reset=True)
@@ -807,7 +809,8 @@ def api_path(wl, iters=60):
             "what": "QuantizeLinear(11008 -> 4096, W4 A8) forward + backward through the module on the step's tensors, F.linear replaced by a "
                     "no-launch stand-in: 1 pair forward launch + 1 pair backward launch (weight gradient in place), wall clock incl. Python / "
                     "autograd / allocator",
-            "stats": {k: v for k, v in st.items() if k.startswith(("pair_", "single_", "inplace_"))},
+            "stats": {k: v for k, v in st.items() if k.startswith(("pair_", "single_", "inplace_", "cpp_"))},
+            "host_node": llm_qat_amd.host_node(),   # which autograd node carried the operand pair: the C++ one (csrc/fq_autograd_node.cpp) or utils_quant's Python node
             "host_ms_per_step": round(host_ms, 4), "gpu_span_ms_per_step": round(gpu_ms, 4),
             "pytorch_floor_ms_per_step": round(dt_floor * 1e3, 4),
             "pytorch_floor_what": "the same loop with a plain module whose forward is only the no-launch stand-in (module call + one autograd Function + "
@@ -820,13 +823,18 @@ def ensure_built(local_rank, dist):
     """A fresh checkout has no libllmqat_fakequant.so yet: compile it (one rank per node does, the others wait).
     Building the product is not a fallback -- without the library the benchmark fails loudly."""
     lib = os.path.join(ROOT, "llm-qat_amd", "libllmqat_fakequant.so")
-    if not os.path.exists(lib) and local_rank == 0:
+    node = os.path.join(ROOT, "llm-qat_amd", "_fq_node.so")
+    if not (os.path.exists(lib) and os.path.exists(node)) and local_rank == 0:
         import importlib.util
         spec = importlib.util.spec_from_file_location("_fq_build", os.path.join(ROOT, "llm-qat_amd", "build.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        print("bench.py: building the HIP library (first run in this checkout)", file=sys.stderr)
+        print("bench.py: building the HIP library / the C++ autograd node (first run in this checkout)", file=sys.stderr)
         mod.build_extension()
+        try:
+            mod.build_node()
+        except Exception as e:  # noqa: BLE001 -- host code only: without it the Python node carries the module path (api_path.host_node says which)
+            print(f"bench.py: the C++ autograd node did not build ({e!r})", file=sys.stderr)
     if dist is not None:
         dist.barrier()
 

@@ -145,7 +145,8 @@ struct FqPairNode : public torch::autograd::Function<FqPairNode> {
         reinterpret_cast<std::atomic<int64_t>*>(m[5])->fetch_add(1, std::memory_order_release);
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &gw = grads[0], &gx = grads[1], &side_w = saved[0], &side_x = saved[1];
-        if (gw.defined() && gx.defined() && side_w.defined() && side_x.defined() && gw.scalar_type() == dtype && gx.scalar_type() == dtype &&
+        if (gw.defined() && gx.defined() && side_w.defined() && side_x.defined() && gw.is_cuda() && gx.is_cuda() && gw.scalar_type() == dtype &&
+            gx.scalar_type() == dtype &&
             !at::GradMode::is_enabled() && gw.is_contiguous() && gx.is_contiguous() &&
             ((reinterpret_cast<uintptr_t>(gw.data_ptr()) | reinterpret_cast<uintptr_t>(gx.data_ptr())) & 15) == 0) {
             const bool inplace = g_inplace.load(std::memory_order_relaxed) && inplace_ok(gw);
@@ -246,6 +247,24 @@ std::pair<at::Tensor, at::Tensor> probe_node(const at::Tensor& weight, const at:
 
 void arm_probe(bool on) { g_probe_armed = on; }
 
+// Measurement stand-in for F.linear (bench.py api_path, tools/api_path_probe.py): a "GEMM" that launches nothing -- forward returns an
+// uninitialised output, backward fresh uninitialised gradients nobody else holds.  In C++ so that the gradients reach the fake-quant node
+// the way F.linear's own do: a tensor a Python function returns keeps its Python wrapper, which the in-place guard counts as a holder.
+struct NoGemm : public torch::autograd::Function<NoGemm> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w) {
+        ctx->save_for_backward({x, w});
+        auto shape = x.sizes().vec();
+        shape.back() = w.size(0);
+        return at::empty(shape, x.options());
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list) {
+        const auto saved = ctx->get_saved_variables();
+        return {at::empty_like(saved[0]), at::empty_like(saved[1])};
+    }
+};
+
+at::Tensor no_gemm_linear(const at::Tensor& x, const at::Tensor& w) { return NoGemm::apply(x, w); }
+
 pybind11::dict baselines() {
     pybind11::dict d;
     for (int v = 0; v < 2; v++)
@@ -271,6 +290,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("pair_node", &pair_node);
     m.def("probe_node", &probe_node);
     m.def("arm_probe", &arm_probe);
+    m.def("no_gemm_linear", &no_gemm_linear);
     m.def("baselines", &baselines);
     m.def("counters", &counters, pybind11::arg("reset") = false);
     m.def("set_inplace", [](bool on) { g_inplace.store(on); });

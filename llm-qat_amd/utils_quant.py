@@ -11,6 +11,7 @@ so `models/modeling_llama_quant.py` (which imports them by name, :51) and everyt
 (`train.py`, `utils/kd_trainer.py`) run unchanged.  The eager ATen op chains are replaced by
 single-pass HIP kernels for gfx950 (see INTEGRATION.md for the one-line switch).
 """
+import ctypes
 import logging
 import os
 import sys
@@ -20,7 +21,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from . import compiled, cpu_tensors, ops
+from . import _node, compiled, cpu_tensors, ops
 
 # How the backward learns which gradients to zero (results are identical in all three modes):
 #   "mask"   (default) the forward records per-row value bounds + a 1-bit/element STE mask for rows
@@ -61,6 +62,27 @@ def _clip_pair(clip_val):
 # ---- counters of what the stateful host logic did (llm_qat_amd.stats()): every optimisation below that can silently fall back says so here
 _stats = {}
 
+# The C++ autograd node (csrc/fq_autograd_node.cpp): QuantizeLinear's straight-line path without Python on the autograd engine's thread.
+# Optional: without the file (or with LLMQAT_AMD_CPP_NODE=0 / cpp_node(False)) the Python `_PairNode` below serves -- same launches, same
+# bits.  It is bound to the kernel library on first use and calibrates its in-place guard at the end of this module.
+_cnode = _node.load()
+_USE_CNODE = _cnode is not None
+
+
+def cpp_node(flag=True):
+    """use the C++ autograd node for QuantizeLinear's operand pair (default: on when _fq_node.so is built)"""
+    global _USE_CNODE
+    _USE_CNODE = bool(flag) and _cnode is not None and _cnode_ready
+    return _USE_CNODE
+
+
+def host_node():
+    """-> "c++" or "python (<why>)": which autograd node QuantizeLinear's straight-line path builds"""
+    return "c++" if _USE_CNODE else "python (%s)" % (_node.status() if _cnode is None else ("guard not calibrated" if not _cnode_ready else "switched off"))
+
+
+_cnode_ready = False
+
 
 def _count(name, n=1):
     _stats[name] = _stats.get(name, 0) + n
@@ -81,10 +103,16 @@ def stats(reset=False):
                                          calls that ran the reference's launch structure because a private torch API the stateful logic
                                          leans on is missing in this build (fail closed; warned once)
       w12_fused_unverified               1-/2-bit weights that took ATen's own abs + mean because the one-launch kernel's restatement of
-                                         ATen's summation order did not verify on this device / torch build"""
+                                         ATen's summation order did not verify on this device / torch build
+      cpp_pair_forward / cpp_pair_backward / cpp_slow_backward
+                                         QuantizeLinear operand pairs served by the C++ autograd node (_fq_node.so; `host_node()` says whether
+                                         it is loaded): launches made from C++, and backwards it handed back to the Python node's code"""
     out = dict(_stats)
     if reset:
         _stats.clear()
+    if _cnode is not None:      # what the C++ node counted (its guard's decisions, its launches): same names
+        for k, v in _cnode.counters(reset).items():
+            out[k] = out.get(k, 0) + v
     return out
 
 
@@ -372,6 +400,8 @@ _INPLACE_WGRAD = os.environ.get("LLMQAT_AMD_INPLACE_WEIGHT_GRAD", "1") != "0"
 def inplace_weight_grad(flag=True):
     global _INPLACE_WGRAD
     _INPLACE_WGRAD = bool(flag)
+    if _cnode is not None:
+        _cnode.set_inplace(_INPLACE_WGRAD)
 
 
 #    This deviates from PyTorch's rule for Function.backward ("never modify grad_outputs in place"), so it is GUARDED at run
@@ -524,7 +554,7 @@ class _ThreadState:
     """Everything the host logic remembers between calls, per FORWARD thread (thread-local: it dies with its thread, so a short-lived
     evaluation or DataParallel replica thread leaves nothing behind).  A backward runs on the autograd engine's threads: its nodes carry
     a weak reference to the state of the thread whose forward built them (`ctx.fq_st`), which is how `_backward_started` reaches it."""
-    __slots__ = ("acts", "outs", "kv", "epoch", "ref", "__weakref__")
+    __slots__ = ("acts", "outs", "kv", "epoch", "ref", "cell", "cepoch", "cseen", "__weakref__")
 
     def __init__(self):
         self.acts = {}        # key -> (weakref(input), its version, its address, _Raw, the result's version, needs grad, region, stream)
@@ -532,6 +562,15 @@ class _ThreadState:
         self.kv = None        # the pending half of a K + V launch
         self.epoch = 0        # fake-quant backward passes started on graphs this thread built
         self.ref = weakref.ref(self)
+        # the C++ node cannot touch this object from the engine's thread: its backward bumps a counter cell instead, and `_state()` --
+        # the first thing every forward call does -- notices and lets go then (the same forgetting, at the thread's next look-up)
+        self.cell = _cnode.epoch_new() if _cnode is not None else 0
+        self.cepoch = ctypes.c_int64.from_address(self.cell) if self.cell else None
+        self.cseen = self.cepoch.value if self.cell else 0
+
+    def __del__(self):
+        if self.cell and _cnode is not None:
+            _cnode.epoch_free(self.cell)   # (a node that outlives its thread bumps a recycled cell: a spurious forgetting, never a stale hit)
 
 
 _tls = threading.local()
@@ -541,7 +580,18 @@ def _state():
     st = getattr(_tls, "st", None)
     if st is None:
         st = _tls.st = _ThreadState()
+    elif st.cepoch is not None and st.cepoch.value != st.cseen:
+        st.cseen = st.cepoch.value
+        _forget(st)
     return st
+
+
+def _forget(st):
+    st.epoch += 1
+    if st.acts:
+        st.acts = {}    # (rebinding, not clearing: the forward thread may be reading the old dict)
+    if st.kv is not None:
+        _kv_discard(st)
 
 
 def _backward_started(ref):
@@ -549,14 +599,10 @@ def _backward_started(ref):
     remembered before (shared activations, a pending V of the K/V hooks) is let go of now -- side buffers included -- and a K/V guess made
     before this point is never honoured afterwards.  Per forward thread, not global: another thread's forward pass (a DataParallel
     replica, an evaluation thread) keeps what it remembered."""
-    st = ref()
-    if st is None:      # the forward thread is gone
+    st = ref() if ref is not None else None
+    if st is None:      # the forward thread is gone (or the C++ node has told its cell already)
         return
-    st.epoch += 1
-    if st.acts:
-        st.acts = {}    # (rebinding, not clearing: the forward thread may be reading the old dict)
-    if st.kv is not None:
-        _kv_discard(st)
+    _forget(st)
 
 
 # The saved-tensor-hooks region API is private (torch._C._autograd._top_saved_tensors_default_hooks).  Without it the host logic cannot
@@ -681,6 +727,7 @@ class _PairNode(torch.autograd.Function):
     def forward(ctx, weight, input, res, code, view_x):
         wq, xq, side_w, side_x, rows_w, rows_x, cols = res
         ctx.fq = (rows_w, rows_x, cols, code, weight.dtype, _state().ref)
+        ctx.fq_foreign = False
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side_w, side_x)  # saved tensors (either may be None): visible to saved-tensor hooks
         # (wq / xq are fresh tensors of the launch that nothing else refers to and become this node's outputs as they are; an xq that a
@@ -700,7 +747,7 @@ class _PairNode(torch.autograd.Function):
     def backward(ctx, gw, gx):
         # (runs on the autograd engine's device thread, where every line of Python costs 2-3x what it costs on the caller's:
         # tools/host_pieces.py -- hence the straight-line fast path for the ordinary case)
-        inplace_w = _INPLACE_WGRAD and gw is not None and _inplace_ok(gw)
+        inplace_w = _INPLACE_WGRAD and gw is not None and not ctx.fq_foreign and _inplace_ok(gw)
         rows_w, rows_x, cols, code, dtype, st = ctx.fq
         _backward_started(st)
         side_w, side_x = ctx.saved_tensors
@@ -718,6 +765,27 @@ class _PairNode(torch.autograd.Function):
             return None, None, None, None, None
         ow, ox = ops.pair_backward(gw, gx, side_w, side_x, rows_w, rows_x, cols, -2.0, 2.0, inplace_w=inplace_w)
         return ow, ox, None, None, None
+
+
+class _CppCtx:
+    """what _PairNode.backward reads from its ctx, for a backward the C++ node hands back (see _pair_backward_from_cpp)"""
+    __slots__ = ("fq", "fq_foreign", "saved_tensors", "needs_input_grad")
+
+
+_CODE_DTYPE = {v: k for k, v in ops._DTYPES.items()}
+
+
+def _pair_backward_from_cpp(gw, gx, side_w, side_x, rows_w, rows_x, cols, code, need_w, need_x):
+    """The C++ node's way out of its straight line (csrc/fq_autograd_node.cpp: a gradient of another dtype or none at all, create_graph,
+    an unaligned gradient): the Python node's backward, called under the GIL on the engine's thread.  Never in place from here -- the
+    reference counts `_inplace_ok` compares are those of a Python Function's arguments -- and the node has told its epoch cell already."""
+    ctx = _CppCtx()
+    ctx.fq = (rows_w, rows_x, cols, code, _CODE_DTYPE[code], None)
+    ctx.fq_foreign = True
+    ctx.saved_tensors = (side_w, side_x)
+    ctx.needs_input_grad = (need_w, need_x, False, False, False)
+    out = _PairNode.backward(ctx, gw, gx)
+    return out[0], out[1]
 
 
 def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
@@ -1025,10 +1093,14 @@ class QuantizeLinear(nn.Linear):
             return None
         weight = self.weight
         plan = self._fq_plan
-        if plan is None or plan[0] != input_.shape or plan[1] is not input_.dtype or plan[2] is not weight.dtype:
+        # (the module's settings are plain attributes a caller may change after construction: they are part of what a plan is valid for)
+        if (plan is None or plan[0] != input_.shape or plan[1] is not input_.dtype or plan[2] is not weight.dtype
+                or plan[4] != (self.w_bits, self.a_bits, self.act_layerwise, self.weight_layerwise, getattr(self, "act_quantizer", None))):
             ok = (3 <= self.w_bits < 32 and 2 < self.a_bits < 32 and getattr(self, "act_quantizer", None) is SymQuantizer and not self.act_layerwise
                   and not self.weight_layerwise)
-            plan = self._fq_plan = (input_.shape, input_.dtype, weight.dtype, ops.pair_plan(weight, input_) if ok else None)
+            plan = self._fq_plan = (input_.shape, input_.dtype, weight.dtype, ops.pair_plan(weight, input_) if ok else None,
+                                    (self.w_bits, self.a_bits, self.act_layerwise, self.weight_layerwise, getattr(self, "act_quantizer", None)),
+                                    (ops.bits_arg(self.w_bits), ops.bits_arg(self.a_bits)) if ok else None)
         pp = plan[3]
         if pp is None or _WEIGHT_CACHE or not (weight.is_contiguous() and input_.is_contiguous()) or input_.is_inference() or weight.is_inference():
             return self._pair_forward_general(input_)
@@ -1056,21 +1128,33 @@ class QuantizeLinear(nn.Linear):
                 wq, side_w, rows_w, cols = res
                 if not (need_w or need_x):
                     return wq, raw.out
+                if _USE_CNODE:
+                    return _cnode.pair_node(weight, input_, wq, raw.out, side_w, raw.saved[0] if need_x else None, rows_w, pp[3], cols, pp[0], True, st.cell)
                 return _PairNode.apply(weight, input_, (wq, raw.out, side_w, raw.saved[0] if need_x else None, rows_w, pp[3], cols), pp[0], True)
         elif _SHARE_ACT:
             _memory_ok("share")   # counts / warns: the region API is missing, nothing is remembered
-        res = ops.pair_forward_planned(weight, input_, pp, self.w_bits, self.a_bits, need_w, need_x, ac)
-        if res is None:
-            return self._pair_forward_general(input_)
+        if _USE_CNODE:
+            # allocations, the launch and the node in one call into C++ (csrc/fq_autograd_node.cpp::pair_forward)
+            w_bits, a_bits = plan[5]
+            out = _cnode.pair_forward(weight, input_, pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], w_bits, a_bits, need_w, need_x, ac,
+                                      ops._SEM_AUTOCAST if ac else ops._semantics, (st if share else _state()).cell)
+            if out is None:
+                return self._pair_forward_general(input_)
+            side_x = out[2]
+        else:
+            res = ops.pair_forward_planned(weight, input_, pp, self.w_bits, self.a_bits, need_w, need_x, ac)
+            if res is None:
+                return self._pair_forward_general(input_)
+            out = _PairNode.apply(weight, input_, res, pp[0], False) if (need_w or need_x) else (res[0], res[1])
+            side_x = res[3]
         _count("pair_launch")
-        out = _PairNode.apply(weight, input_, res, pp[0], False) if (need_w or need_x) else (res[0], res[1])
         if share:
             # remembered for the sibling projections: the data (for a sibling's view of it: _PairNode / _SharedAct) + its side buffer.
             # out[1] is this node's own output tensor when there is a node; siblings never use it as a tensor of their graph.
             _count("act_share_miss")
-            st.acts[key] = (weakref.ref(input_), input_._version, input_.data_ptr(), _Raw(out[1], "mask", (res[3],), (-2.0, 2.0), (pp[3], pp[1])) if need_x
+            st.acts[key] = (weakref.ref(input_), input_._version, input_.data_ptr(), _Raw(out[1], "mask", (side_x,), (-2.0, 2.0), (pp[3], pp[1])) if need_x
                             else _Raw(out[1], "none"), out[1]._version, input_.requires_grad, region, stream)
-        return out
+        return out[0], out[1]
 
     def _pair_forward_general(self, input_):
         """the same decision without a plan: strided operands, the weight cache, inference tensors, dtype mixes (ops.pair_forward's checks)"""
@@ -1182,3 +1266,37 @@ except Exception as _e:  # noqa: BLE001 -- without a baseline _inplace_ok() answ
     _ref_base.clear()
     _log.warning("llm_qat_amd: the in-place weight-gradient guard could not be calibrated (%r): every weight gradient takes the copying "
                  "launch (same results; stats() counts them under inplace_refused:uncalibrated)", _e)
+
+
+def _calibrate_cnode():
+    """The C++ node's in-place guard learns, in its own backward, what the reference counts of a gradient nobody else holds look like
+    (csrc/fq_autograd_node.cpp::inplace_ok): F.linear's wgrad (a view of a temporary), a reshaped one, a plain fresh tensor -- tiny CPU
+    tensors, once at import.  Then the node is bound to the kernel library's entry points and to the Python backward it falls back on."""
+    global _cnode_ready, _USE_CNODE
+    _cnode.arm_probe(True)
+    try:
+        with torch.inference_mode(False), torch.enable_grad():
+            for loss in (lambda wq, xq: nn.functional.linear(xq, wq).sum(), lambda wq, xq: (wq * 2.0).sum() + xq.sum(),
+                         lambda wq, xq: (wq.view(-1) * 2.0).sum() + xq.sum()):
+                w = torch.zeros(2, 4, requires_grad=True)
+                x = torch.zeros(3, 4, requires_grad=True)
+                loss(*_cnode.probe_node(w, x)).backward()
+    finally:
+        _cnode.arm_probe(False)
+    base = _cnode.baselines()
+    if "view" not in base or "plain" not in base:
+        raise RuntimeError(f"reference-count baselines incomplete: {base}")
+    _cnode.set_inplace(_INPLACE_WGRAD)
+    if not _node.bind(_pair_backward_from_cpp):
+        raise RuntimeError("could not bind the node to the kernel library")
+    _cnode_ready = True
+    _USE_CNODE = True
+
+
+if _cnode is not None:
+    _USE_CNODE = False
+    try:
+        _calibrate_cnode()
+    except Exception as _e:  # noqa: BLE001 -- the Python node serves (same launches, same results); host_node() says why
+        _log.warning("llm_qat_amd: the C++ autograd node is not used (%r): QuantizeLinear builds its Python node", _e)
+

@@ -1,0 +1,230 @@
+"""GPU tier: the C++ autograd node behind QuantizeLinear's operand pair (llm-qat_amd/csrc/fq_autograd_node.cpp, `_fq_node.so`) against the
+Python `_PairNode` it stands in for -- same launches, so every output and gradient must be the same bits -- and against the live eager
+chain; what each node did is read from llm_qat_amd.stats().  The node must be LOADED on a GPU box (host_node() == "c++"): a missing or
+stale `_fq_node.so` fails these tests instead of quietly testing the Python node twice."""
+import os
+import sys
+import threading
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tiny_llama as TL  # noqa: E402
+
+
+@pytest.fixture()
+def pkg():
+    import llm_qat_amd
+    assert llm_qat_amd.host_node() == "c++", llm_qat_amd.host_node()
+    llm_qat_amd.set_semantics("device_eager")
+    llm_qat_amd.reset_learned_state()
+    yield llm_qat_amd
+    llm_qat_amd.cpp_node(True)
+    llm_qat_amd.set_semantics("cpu_eager")
+    llm_qat_amd.reset_learned_state()
+
+
+def mk(Q, d_in, d_out, dtype, w_bits=4, a_bits=8, seed=0):
+    m = Q.QuantizeLinear(d_in, d_out, w_bits=w_bits, a_bits=a_bits).cuda().to(dtype)
+    with torch.no_grad():
+        m.weight.copy_((torch.randn(d_out, d_in, generator=torch.Generator().manual_seed(50 + seed)) * 0.5).cuda().to(dtype))
+        m.weight[1, 3], m.weight[d_out - 1, d_in - 1] = 2.5, -3.0     # beyond the STE clip: these gradients are masked
+    return m
+
+
+def step(m, x, autocast, loss_scale=1.0):
+    m.weight.grad = None
+    if x.requires_grad:
+        x.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = m(x)
+    if y.requires_grad:
+        (y.float().square().sum() * loss_scale).backward()
+    return y.detach(), m.weight.grad, x.grad if x.requires_grad else None
+
+
+def same(a, b):
+    return (a is None and b is None) or (a is not None and b is not None and a.dtype == b.dtype and torch.equal(a, b))
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(4, 9, 264), (33, 512), (2, 3, 5, 64)])
+def test_both_nodes_give_the_eager_chains_bits(pkg, dtype, autocast, shape):
+    from llm_qat_amd import utils_quant as U
+    d_in = shape[-1]
+    x0 = (torch.randn(*shape, generator=torch.Generator().manual_seed(1)) * 1.4).cuda().to(dtype)
+    res = {}
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            assert pkg.cpp_node(impl == "c++") == (impl == "c++")
+        for need_w, need_x in ((True, True), (True, False), (False, True), (False, False)):
+            m = mk(Q, d_in, 48, dtype)
+            m.weight.requires_grad_(need_w)
+            x = x0.clone().requires_grad_(need_x)
+            pkg.stats(reset=True)
+            res[impl, need_w, need_x] = step(m, x, autocast)
+            st = pkg.stats(reset=True)
+            if impl == "c++" and len(shape) <= 3 and not (autocast and dtype is torch.float16):
+                assert st.get("cpp_pair_forward") == 1 and (st.get("cpp_pair_backward", 0) == 1) == (need_w and need_x), (st, need_w, need_x)
+            if impl == "python":
+                assert not any(k.startswith("cpp_") for k in st), st
+    for key, want in res.items():
+        if key[0] == "eager":
+            for impl in ("c++", "python"):
+                got = res[(impl,) + key[1:]]
+                assert all(same(a, b) for a, b in zip(got, want)), (impl, key, dtype, autocast)
+
+
+def test_one_operand_without_a_gradient_takes_the_python_backward(pkg):
+    """the straight line is "both gradients arrive": a frozen weight (or an input without grad) leaves the C++ node one gradient, which it
+    hands to the Python node's code -- counted, same bits as the Python node"""
+    from llm_qat_amd import utils_quant as U
+    out = {}
+    for impl in ("c++", "python"):
+        pkg.cpp_node(impl == "c++")
+        m = mk(U, 256, 64, torch.bfloat16)
+        m.weight.requires_grad_(False)
+        x = (torch.randn(8, 256, generator=torch.Generator().manual_seed(2)) * 1.3).cuda().bfloat16().requires_grad_(True)
+        pkg.stats(reset=True)
+        out[impl] = step(m, x, False)
+        st = pkg.stats(reset=True)
+        assert (st.get("cpp_slow_backward", 0) == 1) == (impl == "c++"), st
+    assert all(same(a, b) for a, b in zip(out["c++"], out["python"]))
+
+
+def test_create_graph_goes_through_the_python_backward(pkg):
+    """a backward that is itself recorded (create_graph=True) is outside the node's straight line: utils_quant's graph-aware backward
+    serves it under the GIL -- gradient and gradient-of-gradient equal the Python node's and the eager chain's"""
+    from llm_qat_amd import utils_quant as U
+    res = {}
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            pkg.cpp_node(impl == "c++")
+        m = mk(Q, 128, 32, torch.float32)
+        x = (torch.randn(6, 128, generator=torch.Generator().manual_seed(4)) * 1.3).cuda().requires_grad_(True)
+        pkg.stats(reset=True)
+        y = m(x)
+        gx, gw = torch.autograd.grad(y.square().sum(), [x, m.weight], create_graph=True)
+        ggx, = torch.autograd.grad((gx * gx).sum() + (gw * gw).sum(), [x], allow_unused=True)
+        res[impl] = (y.detach(), gx.detach(), gw.detach(), ggx)
+        st = pkg.stats(reset=True)
+        if impl == "c++":
+            assert st.get("cpp_slow_backward", 0) >= 1, st
+    for impl in ("c++", "python"):
+        assert all(same(a, b) for a, b in zip(res[impl], res["eager"])), impl
+
+
+def test_sibling_sharing_forgets_at_the_next_forward_after_a_backward(pkg):
+    """the C++ node tells its forward thread's epoch cell that a backward began; the thread lets go of what it remembered at its next
+    look-up: a sibling called after the backward, on the same input, quantizes again (a miss) -- as with the Python node"""
+    from llm_qat_amd import utils_quant as U
+    for impl in ("c++", "python"):
+        pkg.cpp_node(impl == "c++")
+        pkg.reset_learned_state()
+        q, k = mk(U, 128, 64, torch.bfloat16, seed=1), mk(U, 128, 64, torch.bfloat16, seed=2)
+        x = (torch.randn(5, 128, generator=torch.Generator().manual_seed(5)) * 1.2).cuda().bfloat16().requires_grad_(True)
+        pkg.stats(reset=True)
+        a, b = q(x), k(x)
+        st = pkg.stats(reset=True)
+        assert st.get("act_share_miss") == 1 and st.get("act_share_hit") == 1, (impl, st)
+        (a.float().sum() + b.float().sum()).backward()
+        pkg.stats(reset=True)
+        c = k(x)                      # same tensor, same version: only the backward in between makes this a miss
+        st = pkg.stats(reset=True)
+        assert st.get("act_share_miss") == 1 and not st.get("act_share_hit"), (impl, st)
+        assert torch.equal(c, b)
+        assert not U._state().acts or len(U._state().acts) == 1
+
+
+def test_settings_changed_after_construction_are_honoured(pkg):
+    """w_bits / a_bits are plain attributes in the reference (models/utils_quant.py:177-178) and a caller may change them: the per-module
+    launch plan is valid for the settings it was made under, not for the module"""
+    from llm_qat_amd import utils_quant as U
+    E = TL.EagerQuant()
+    x = (torch.randn(7, 256, generator=torch.Generator().manual_seed(6)) * 1.2).cuda().bfloat16()
+    for impl in ("c++", "python"):
+        pkg.cpp_node(impl == "c++")
+        m, e = mk(U, 256, 64, torch.bfloat16), mk(E, 256, 64, torch.bfloat16)
+        for w_bits, a_bits in ((4, 8), (8, 8), (3, 8), (4, 4), (8, 6), (4, 8)):      # (the eager twin serves the w_bits >= 3 branch)
+            m.w_bits = e.w_bits = w_bits
+            m.a_bits = e.a_bits = a_bits
+            xs = [x.clone().requires_grad_(True) for _ in range(2)]
+            got, want = step(m, xs[0], False), step(e, xs[1], False)
+            assert all(same(a, b) for a, b in zip(got, want)), (impl, w_bits, a_bits)
+
+
+def test_backward_on_another_stream_and_device_thread(pkg):
+    """the node launches on the stream that is current where its backward runs (the engine sets the forward's stream): a forward + backward
+    under a side stream, from a second Python thread, equals the default-stream result"""
+    from llm_qat_amd import utils_quant as U
+    m = mk(U, 512, 128, torch.bfloat16)
+    x0 = (torch.randn(64, 512, generator=torch.Generator().manual_seed(7)) * 1.2).cuda().bfloat16()
+    want = step(m, x0.clone().requires_grad_(True), False)
+    want = tuple(t.clone() for t in want)
+    got = {}
+
+    def work():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.default_stream())
+        with torch.cuda.stream(s):
+            x = x0.clone().requires_grad_(True)
+            got["r"] = tuple(t.clone() for t in step(m, x, False))
+        s.synchronize()
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert all(same(a, b) for a, b in zip(got["r"], want))
+
+
+def test_saved_tensor_hooks_see_the_side_buffers(pkg):
+    """the side buffers (row bounds + STE mask) are saved through the autograd context in C++ as in Python: saved-tensor hooks
+    (checkpointing, CPU offload) get to pack and unpack them"""
+    from llm_qat_amd import utils_quant as U
+    out = {}
+    for impl in ("c++", "python"):
+        pkg.cpp_node(impl == "c++")
+        m = mk(U, 256, 64, torch.bfloat16)
+        x = (torch.randn(8, 256, generator=torch.Generator().manual_seed(8)) * 1.3).cuda().bfloat16().requires_grad_(True)
+        packed = []
+
+        def pack(t):
+            packed.append((t.dtype, t.numel()))
+            return t.cpu()
+
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t.cuda()):
+            y = m(x)
+        y.float().square().sum().backward()
+        out[impl] = (y.detach(), m.weight.grad.clone(), x.grad.clone(), sorted(n for d, n in packed if d is torch.uint8))
+        assert len(out[impl][3]) == 2, packed     # the two side buffers went through the hooks
+    assert all(same(a, b) for a, b in zip(out["c++"][:3], out["python"][:3])) and out["c++"][3] == out["python"][3]
+
+
+def test_checkpointed_block_with_siblings(pkg):
+    """non-reentrant and reentrant checkpoint around a block of sibling projections: first pass and recompute build the same nodes"""
+    from torch.utils.checkpoint import checkpoint
+    from llm_qat_amd import utils_quant as U
+    res = {}
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            pkg.cpp_node(impl == "c++")
+        for reentrant in (False, True):
+            pkg.reset_learned_state()
+            q, k, o = mk(Q, 128, 128, torch.bfloat16, seed=1), mk(Q, 128, 128, torch.bfloat16, seed=2), mk(Q, 128, 128, torch.bfloat16, seed=3)
+            x = (torch.randn(4, 6, 128, generator=torch.Generator().manual_seed(9)) * 1.2).cuda().bfloat16().requires_grad_(True)
+
+            def block(t):
+                return o(F.silu(q(t)) * k(t))
+            y = checkpoint(block, x, use_reentrant=reentrant)
+            y.float().square().sum().backward()
+            res[impl, reentrant] = (y.detach(), x.grad.clone(), q.weight.grad.clone(), k.weight.grad.clone(), o.weight.grad.clone())
+    for impl in ("c++", "python"):
+        for reentrant in (False, True):
+            assert all(same(a, b) for a, b in zip(res[impl, reentrant], res["eager", reentrant])), (impl, reentrant)

@@ -82,13 +82,15 @@ MISSING = {
 }
 
 
+@pytest.mark.parametrize("node", ["c++", "python"])
 @pytest.mark.parametrize("autocast", [False, True])
 @pytest.mark.parametrize("missing", list(MISSING))
-def test_missing_private_api_switches_the_feature_off(monkeypatch, missing, autocast):
+def test_missing_private_api_switches_the_feature_off(monkeypatch, missing, autocast, node):
     import llm_qat_amd
     import llm_qat_amd.utils_quant as UQ
     attr, counters = MISSING[missing]
     llm_qat_amd.set_semantics("device_eager")
+    assert llm_qat_amd.cpp_node(node == "c++") == (node == "c++"), llm_qat_amd.host_node()
     try:
         want = [p(TL.EagerQuant(), autocast) for p in PROGRAMS]
         monkeypatch.setattr(UQ, attr, None)
@@ -98,6 +100,11 @@ def test_missing_private_api_switches_the_feature_off(monkeypatch, missing, auto
         st = llm_qat_amd.stats()
         for p, w, g in zip(PROGRAMS, want, got):
             assert same(w, g), f"{missing}: {p.__name__}"
+        if missing == "no_storage_use_count" and node == "c++":
+            # the C++ node's guard reads the reference counts through the public C++ API (Tensor::use_count, Storage::use_count): it does
+            # not lean on this private Python API at all (what it refuses: test_gpu_features.py::test_inplace_weight_gradient_is_guarded)
+            assert st.get("cpp_pair_backward", 0) > 0 and st.get("inplace_taken", 0) > 0 and not st.get("inplace_refused:no_refcount_api"), st
+            return
         for c in counters:
             assert st.get(c, 0) > 0, (c, st)
         if missing == "no_region_api":     # nothing remembered: no sharing, no K/V speculation
@@ -107,6 +114,7 @@ def test_missing_private_api_switches_the_feature_off(monkeypatch, missing, auto
         if missing == "no_storage_use_count":
             assert not st.get("inplace_taken"), st
     finally:
+        llm_qat_amd.cpp_node(True)
         llm_qat_amd.set_semantics("cpu_eager")
         llm_qat_amd.reset_learned_state()
 

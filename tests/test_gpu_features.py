@@ -174,14 +174,23 @@ class Counter:
     (ops.pair_forward_planned / pair_backward_planned: same launches)"""
     TWINS = {"pair_forward": "pair_forward_planned", "pair_backward": "pair_backward_planned"}
 
+    CPP = {"pair_forward": "cpp_pair_forward", "pair_backward": "cpp_pair_backward"}   # the C++ node's own launches of the same entry points
+
     def __init__(self, mod, names):
         self.mod, self.n = mod, 0
         self.names = list(names) + [self.TWINS[n] for n in names if n in self.TWINS and hasattr(mod, self.TWINS[n])]
+        self.cpp = [self.CPP[n] for n in names if n in self.CPP]
+
+    def _cpp_counts(self):
+        from llm_qat_amd import utils_quant as U
+        c = U._cnode.counters() if U._cnode is not None else {}
+        return sum(c.get(k, 0) for k in self.cpp)
 
     def __enter__(self):
         self.orig = {n: getattr(self.mod, n) for n in self.names}
         for n, f in self.orig.items():
             setattr(self.mod, n, self._wrap(f))
+        self.cpp0 = self._cpp_counts()
         return self
 
     def _wrap(self, f):
@@ -193,6 +202,7 @@ class Counter:
     def __exit__(self, *exc):
         for n, f in self.orig.items():
             setattr(self.mod, n, f)
+        self.n += self._cpp_counts() - self.cpp0
 
 
 def qkv_loss(mods, x):
@@ -1114,24 +1124,27 @@ def test_frozen_operand_gets_a_result_that_needs_no_grad(pkg):
     lin = QuantizeLinear(1024, 512, w_bits=4, a_bits=8).cuda().bfloat16()
     x = torch.randn(8, 1024, device="cuda").bfloat16()
     seen = {}
-    orig = U._PairNode.apply
+    orig = torch.nn.functional.linear
 
-    def spy(*a):
-        r = orig(*a)
-        seen["req"] = (r[0].requires_grad, r[1].requires_grad)
-        return r
+    def spy(inp, w, b=None):          # what the module hands to F.linear: (quantized weight, quantized input)
+        seen["req"] = (w.requires_grad, inp.requires_grad)
+        return orig(inp, w, b)
 
-    U._PairNode.apply = spy
-    try:
-        lin.weight.requires_grad_(False)
-        xg = x.clone().requires_grad_(True)
-        lin(xg).float().sum().backward()
-        assert seen["req"] == (False, True) and xg.grad is not None and lin.weight.grad is None
-        lin.weight.requires_grad_(True)
-        lin(x).float().sum().backward()
-        assert seen["req"] == (True, False) and lin.weight.grad is not None
-    finally:
-        U._PairNode.apply = orig
+    for node in ("c++", "python"):
+        assert pkg.cpp_node(node == "c++") == (node == "c++"), pkg.host_node()
+        torch.nn.functional.linear = spy
+        try:
+            lin.weight.grad = None
+            lin.weight.requires_grad_(False)
+            xg = x.clone().requires_grad_(True)
+            lin(xg).float().sum().backward()
+            assert seen["req"] == (False, True) and xg.grad is not None and lin.weight.grad is None, node
+            lin.weight.requires_grad_(True)
+            lin(x).float().sum().backward()
+            assert seen["req"] == (True, False) and lin.weight.grad is not None, node
+        finally:
+            torch.nn.functional.linear = orig
+            pkg.cpp_node(True)
 
 
 def test_autocast_dtype_differs_from_tensor_dtype(pkg):
@@ -1197,31 +1210,33 @@ def test_weight_cache_with_autocast_dtype_mismatch_gradients(pkg, cols):
                 assert torch.equal(xa, xb) and torch.equal(wa, wb), (tdt, adt, cache, inplace, pairing)
 
 
-def test_inplace_weight_gradient_is_guarded(pkg):
+@pytest.mark.parametrize("node", ["c++", "python"])
+def test_inplace_weight_gradient_is_guarded(pkg, node):
     """VERDICT r02 item 10 / ADVICE: handing F.linear's wgrad on by reference (masked in place) deviates from PyTorch's "never
     modify grad_outputs in place" rule; it is taken only when the gradient tensor owns its whole storage (no view, offset 0,
     contiguous) and nobody can observe it: a tensor hook or retain_grad() on the quantized weight, anomaly mode, or a view into a
-    larger buffer fall back to the copy.  Gradients are identical either way; observers see the UNMASKED gradient they are entitled to."""
+    larger buffer fall back to the copy.  Gradients are identical either way; observers see the UNMASKED gradient they are entitled to.
+    Both autograd nodes (the C++ one of csrc/fq_autograd_node.cpp with its guard on C++ reference counts, the Python `_PairNode`):
+    what the guard decided is read from llm_qat_amd.stats()."""
     from llm_qat_amd import utils_quant as U
     from llm_qat_amd.utils_quant import QuantizeLinear
+    assert pkg.cpp_node(node == "c++") == (node == "c++"), pkg.host_node()
+    try:
+        _inplace_guard_body(pkg, U, QuantizeLinear, node)
+    finally:
+        pkg.cpp_node(True)
+        pkg.inplace_weight_grad(True)
+
+
+def _inplace_guard_body(pkg, U, QuantizeLinear, node):
     torch.manual_seed(13)
     lin = QuantizeLinear(512, 128, w_bits=4, a_bits=8).cuda().bfloat16()
     with torch.no_grad():
         lin.weight[7, 9] = 2.25          # a weight element beyond the clip: its gradient is masked
     x = (torch.randn(16, 512, device="cuda") * 1.2).bfloat16().requires_grad_(True)
 
-    flags = []
-    orig_pb, orig_pbp = U.ops.pair_backward, U.ops.pair_backward_planned
-
-    def pb_spy(*a, inplace_w=False, **k):
-        flags.append(bool(inplace_w))
-        return orig_pb(*a, inplace_w=inplace_w, **k)
-
-    def pbp_spy(*a):                      # the module's lean twin: inplace_w is its last positional argument
-        flags.append(bool(a[-1]))
-        return orig_pbp(*a)
-
-    def grads(hook=None):
+    def grads(hook=None, anomaly=False):
+        """-> weight grad, input grad, what the hook saw, the guard's decision (True: in place, False: refused, None: not asked)"""
         lin.weight.grad = x.grad = None
         seen = {}
         orig = torch.nn.functional.linear
@@ -1233,30 +1248,39 @@ def test_inplace_weight_gradient_is_guarded(pkg):
                 w.register_hook(lambda g: seen.__setitem__("g", g))      # keeps the very tensor the node is about to receive
             return orig(inp, w, b)
         torch.nn.functional.linear = spy
-        U.ops.pair_backward, U.ops.pair_backward_planned = pb_spy, pbp_spy
+        pkg.stats(reset=True)
         try:
-            y = lin(x)
-            y.float().square().sum().backward()
+            with torch.autograd.set_detect_anomaly(anomaly, check_nan=False):
+                y = lin(x)
+                y.float().square().sum().backward()
         finally:
             torch.nn.functional.linear = orig
-            U.ops.pair_backward, U.ops.pair_backward_planned = orig_pb, orig_pbp
-        return lin.weight.grad.clone(), x.grad.clone(), seen.get("g")
+        st = pkg.stats(reset=True)
+        assert (st.get("cpp_pair_backward", 0) == 1) == (node == "c++"), (node, st)
+        refused = [k for k in st if k.startswith("inplace_refused")]
+        took = True if st.get("inplace_taken") else (False if refused else None)
+        return lin.weight.grad.clone(), x.grad.clone(), seen.get("g"), took, refused
 
     pkg.inplace_weight_grad(False)
-    want_w, want_x, _ = grads()
-    assert flags == [False]
+    want_w, want_x, _, took, _ = grads()
+    assert took is None
     pkg.inplace_weight_grad(True)
-    got_w, got_x, _ = grads()
-    assert flags[-1] is True, "the guarded in-place path never engages in the plain module flow: the guard is miscalibrated on this device"
+    got_w, got_x, _, took, why = grads()
+    assert took is True, f"the guarded in-place path never engages in the plain module flow: the guard is miscalibrated on this device ({why})"
     assert torch.equal(got_w, want_w) and torch.equal(got_x, want_x) and got_w[7, 9] == 0
     # a hook that clones: it observes the gradient BEFORE the STE mask (as with the reference's clone): not zero at [7, 9]
-    got_w, got_x, seen = grads(hook="clone")
+    got_w, got_x, seen, took, _ = grads(hook="clone")
     assert torch.equal(got_w, want_w) and torch.equal(got_x, want_x)
     assert seen is not None and seen[7, 9] != 0, "the hook saw a gradient that had already been masked in place"
     # a hook that keeps the tensor itself: somebody else holds the gradient -> the node copies, the stashed tensor stays unmasked
-    got_w, got_x, seen = grads(hook="stash")
-    assert flags[-1] is False and torch.equal(got_w, want_w) and torch.equal(got_x, want_x)
+    got_w, got_x, seen, took, why = grads(hook="stash")
+    assert took is False and torch.equal(got_w, want_w) and torch.equal(got_x, want_x), why
     assert seen[7, 9] != 0, "a gradient someone else holds was modified in place"
+    # anomaly mode keeps gradients for its diagnostics: never in place
+    got_w, got_x, _, took, why = grads(anomaly=True)
+    assert took is False and why == ["inplace_refused:anomaly"] and torch.equal(got_w, want_w) and torch.equal(got_x, want_x), why
+    if node == "c++":
+        return
     # the ownership test itself
     g = torch.randn(128, 512, device="cuda").bfloat16()
     assert U._owns_storage(g)

@@ -36,8 +36,16 @@ class LaunchCounter:
         from llm_qat_amd import _lib
         self.L, self.n = _lib.lib(), {}
 
+    @staticmethod
+    def _cpp():
+        """launches the C++ autograd node made itself (it calls the same two entry points through their addresses)"""
+        from llm_qat_amd import utils_quant as U
+        c = U._cnode.counters() if U._cnode is not None else {}
+        return {"fq_sym_fwd_pair": c.get("cpp_pair_forward", 0), "fq_ste_bwd_mask_pair": c.get("cpp_pair_backward", 0)}
+
     def __enter__(self):
         self.orig = {}
+        self.cpp0 = self._cpp()
         for name in LAUNCHING:
             f = getattr(self.L, name)
             self.orig[name] = f
@@ -51,6 +59,9 @@ class LaunchCounter:
     def __exit__(self, *exc):
         for name, f in self.orig.items():
             setattr(self.L, name, f)
+        for name, v in self._cpp().items():
+            if v - self.cpp0[name]:
+                self.n[name] = self.n.get(name, 0) + v - self.cpp0[name]
 
     @property
     def forward(self):

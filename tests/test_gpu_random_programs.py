@@ -2,7 +2,7 @@
 32, a_bits incl. off, Sym / Asym, layerwise flags), KV-hook style SymQuantizer.apply calls, elementwise glue, no_grad regions, tensors that
 do or do not require grad, widths that the vector kernels serve and widths they do not, some steps under activation checkpointing, then
 backpropagates a random loss -- and runs it twice, the drop-in under a random configuration (backward mode, conservative, weight cache,
-K/V pairing, in-place weight gradients: none of which may change a result): on the live eager chain (tiny_llama.EagerQuant over
+K/V pairing, in-place weight gradients, the C++ or the Python autograd node: none of which may change a result): on the live eager chain (tiny_llama.EagerQuant over
 oracle/eager_chain.py, plus the 1-/2-bit branch's op chain) and on the drop-in at default settings.
 
 What must hold for every program: the same outputs bit for bit; the same set of tensors receiving a gradient; every gradient bit for bit,
@@ -95,7 +95,9 @@ def gen_program(rng):
                     checkpoint=rng.choice([None, None, "reentrant", "nonreentrant"]), pair_kv=rng.random() < 0.85, inplace=rng.random() < 0.85,
                     second_backward=rng.random() < 0.2, grad_hooks=rng.random() < 0.3, dtype=rng.choice(["bf16", "bf16", "fp16", "fp32"]),
                     autocast_dtype=rng.choice(["bf16", "bf16", "fp16"]))
-    return mods, inputs, steps, loss, rng.random() < 0.5, settings
+    ac = rng.random() < 0.5
+    settings["cpp_node"] = rng.random() < 0.6      # which autograd node QuantizeLinear's operand pair builds (drawn last: older seeds keep their programs)
+    return mods, inputs, steps, loss, ac, settings
 
 
 def run_program(Q, eager, prog, device="cuda"):
@@ -183,9 +185,11 @@ def check_program(seed, share):
             llm_qat_amd.inplace_weight_grad(cfg["inplace"])
             llm_qat_amd.enable_weight_quant_cache(cfg["weight_cache"] is not None, persistent=cfg["weight_cache"] == "persistent")
         llm_qat_amd.set_backward_mode(cfg["backward_mode"])
+        llm_qat_amd.cpp_node(cfg["cpp_node"])
         llm_qat_amd.reset_learned_state()
         got_o, got_g = run_program(UQ, False, prog)
     finally:
+        llm_qat_amd.cpp_node(True)
         llm_qat_amd.set_backward_mode(prev_mode)
         llm_qat_amd.conservative(False)
         llm_qat_amd.enable_weight_quant_cache(False)

@@ -18,6 +18,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiny_llama as TL  # noqa: E402
 
 
+@pytest.fixture(autouse=True, params=["c++", "python"])
+def node(request):
+    """every test of this file with either autograd node behind QuantizeLinear's operand pair (csrc/fq_autograd_node.cpp / _PairNode)"""
+    import llm_qat_amd
+    assert llm_qat_amd.cpp_node(request.param == "c++") == (request.param == "c++"), llm_qat_amd.host_node()
+    yield request.param
+    llm_qat_amd.cpp_node(True)
+
+
 def fq_nodes(outs):
     """the distinct fake-quant autograd nodes that feed x into the GEMMs behind `outs` (walked with the node objects held: ids of
     temporaries get reused)"""
@@ -27,7 +36,7 @@ def fq_nodes(outs):
         if n is None or any(n is s for s in seen):
             continue
         seen.append(n)
-        if any(k in type(n).__name__ for k in ("_SharedAct", "_PairNode")):   # the nodes an activation's gradient passes through
+        if any(k in n.name() for k in ("_SharedAct", "_PairNode", "FqPairNode")):   # the nodes an activation's gradient passes through (Python / C++)
             found.append(n)
             continue
         todo.extend(f for f, _ in n.next_functions)

@@ -148,9 +148,11 @@ def test_random_programs_on_the_cpu_path_equal_the_live_reference():
                         llm_qat_amd.share_activation_quant(share)
                         llm_qat_amd.enable_weight_quant_cache(cfg["weight_cache"] is not None, persistent=cfg["weight_cache"] == "persistent")
                     llm_qat_amd.set_backward_mode(cfg["backward_mode"])
+                    llm_qat_amd.cpp_node(cfg["cpp_node"])
                     llm_qat_amd.reset_learned_state()
                     got_o, got_g = RP.run_program(UQ, False, prog, device="cpu")
                 finally:
+                    llm_qat_amd.cpp_node(True)
                     llm_qat_amd.set_backward_mode(prev)
                     llm_qat_amd.conservative(False)
                     llm_qat_amd.enable_weight_quant_cache(False)

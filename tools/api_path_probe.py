@@ -39,7 +39,9 @@ for k in range(nsets):
     lins.append((lin, a))
 go = torch.empty(rows, rows, dtype=torch.bfloat16, device=dev)
 real = F.linear
-F.linear = torch.nn.functional.linear = lambda x, w, b=None: _NoGemm.apply(x, w)
+import llm_qat_amd.utils_quant as _UQ
+no_gemm = _UQ._cnode.no_gemm_linear if _UQ._cnode is not None else _NoGemm.apply   # (the C++ stand-in: its gradients arrive without a Python wrapper, as a GEMM's do)
+F.linear = torch.nn.functional.linear = lambda x, w, b=None: no_gemm(x, w)
 N = int(os.environ.get("N", "40"))
 
 
@@ -75,11 +77,16 @@ def loop(mods, n):
 floors = [(_Floor(l), a) for l, a in lins]
 loop(floors, 8)
 print("floor (module + one no-launch Function + engine): host fwd %.1f us, host bwd %.1f us, wall %.1f us/step, GPU %.1f us/step" % loop(floors, N))
-for name, setup in (("default", lambda: llm_qat_amd.conservative(False)), ("conservative", lambda: llm_qat_amd.conservative(True))):
-    setup()
-    loop(lins, 8)
-    print("%-12s host fwd %.1f us, host bwd %.1f us, wall %.1f us/step, GPU %.1f us/step" % ((name,) + loop(lins, N)))
+print("autograd node of the operand pair:", llm_qat_amd.host_node())
+for rnd in range(int(os.environ.get("ROUNDS", "2"))):     # interleaved: the host's speed drifts over a run
+    for name, setup in (("default, C++ node", lambda: (llm_qat_amd.conservative(False), llm_qat_amd.cpp_node(True))),
+                        ("default, Python node", lambda: (llm_qat_amd.conservative(False), llm_qat_amd.cpp_node(False))),
+                        ("conservative", lambda: llm_qat_amd.conservative(True))):
+        setup()
+        loop(lins, 8)
+        print("%-22s host fwd %.1f us, host bwd %.1f us, wall %.1f us/step, GPU %.1f us/step" % ((name,) + loop(lins, N)))
 llm_qat_amd.conservative(False)
+llm_qat_amd.cpp_node(True)
 tf = tb = 0.0
 for k in range(8):
     lin, a = lins[k % nsets]

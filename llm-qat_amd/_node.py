@@ -31,6 +31,10 @@ def load():
         _why = "not built (python llm-qat_amd/build.py)"
         return None
     try:
+        import torch
+        built_for = open(NODE_PATH + ".built_for").read().strip() if os.path.exists(NODE_PATH + ".built_for") else "?"
+        if built_for != torch.__version__:      # a C++ extension is tied to the PyTorch it was compiled against: never load it under another one
+            raise RuntimeError(f"built for PyTorch {built_for}, this is {torch.__version__}: run python llm-qat_amd/build.py")
         spec = importlib.util.spec_from_file_location("_fq_node", NODE_PATH)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

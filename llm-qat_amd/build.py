@@ -60,7 +60,10 @@ NODE_DEPS = [NODE_SRC, os.path.join(os.path.dirname(HERE), "include", "llmqat_fa
 
 
 def node_up_to_date():
-    return os.path.exists(NODE_LIB) and all(os.path.getmtime(NODE_LIB) >= os.path.getmtime(d) for d in NODE_DEPS)
+    if not (os.path.exists(NODE_LIB) and os.path.exists(NODE_LIB + ".built_for")):
+        return False
+    import torch
+    return open(NODE_LIB + ".built_for").read().strip() == torch.__version__ and all(os.path.getmtime(NODE_LIB) >= os.path.getmtime(d) for d in NODE_DEPS)
 
 
 def build_node(force=False, verbose=False):
@@ -81,6 +84,8 @@ def build_node(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(NODE_LIB + ".built_for", "w") as f:     # the loader refuses the file under another PyTorch instead of dlopen()ing it and hoping
+        f.write(torch.__version__ + "\n")
     return NODE_LIB
 
 

@@ -12,7 +12,8 @@ import os
 from . import _lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NODE_PATH = os.path.join(HERE, "_fq_node.so")
+# LLMQAT_AMD_NODE points the loader at another build of the node (a sanitizer build: tests/README.md), as LLMQAT_AMD_LIB does for the kernels
+NODE_PATH = os.environ.get("LLMQAT_AMD_NODE") or os.path.join(HERE, "_fq_node.so")
 
 _mod = None
 _why = None

@@ -192,6 +192,8 @@ std::pair<at::Tensor, at::Tensor> pair_node(const at::Tensor& weight, const at::
                                             const c10::optional<at::Tensor>& side_w, const c10::optional<at::Tensor>& side_x, int64_t rows_w,
                                             int64_t rows_x, int64_t cols, int64_t code, bool view_x, int64_t epoch) {
     const bool grad = at::GradMode::is_enabled();
+    TORCH_CHECK(epoch != 0, "llm_qat_amd: pair_node needs its forward thread's epoch cell");
+    if (!(grad && (weight.requires_grad() || input.requires_grad()))) return {wq, xq};
     PairArgs a{wq, xq, side_w.value_or(at::Tensor()), side_x.value_or(at::Tensor()), view_x, grad && weight.requires_grad(),
                grad && input.requires_grad(), rows_w, rows_x, cols, code, epoch};
     auto out = FqPairNode::apply(weight, input, &a);
@@ -203,6 +205,7 @@ std::pair<at::Tensor, at::Tensor> pair_node(const at::Tensor& weight, const at::
 pybind11::object pair_forward(const at::Tensor& weight, const at::Tensor& input, int64_t code, int64_t cols, int64_t rows_w, int64_t rows_x, int64_t mw,
                               int64_t mx, int64_t w_bits, int64_t a_bits, bool need_w, bool need_x, bool ac, int64_t sem, int64_t epoch) {
     TORCH_CHECK(g_fwd_pair != nullptr, "llm_qat_amd: _fq_node is not bound to the kernel library");
+    TORCH_CHECK(epoch != 0, "llm_qat_amd: pair_forward needs its forward thread's epoch cell");
     TORCH_CHECK(weight.is_contiguous() && input.is_contiguous() && weight.scalar_type() == input.scalar_type() && dtype_code(weight.scalar_type()) == code &&
                     weight.numel() == rows_w * cols && input.numel() == rows_x * cols && weight.device() == input.device(),
                 "llm_qat_amd: pair_forward called with operands its plan does not describe");
@@ -294,6 +297,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("baselines", &baselines);
     m.def("counters", &counters, pybind11::arg("reset") = false);
     m.def("set_inplace", [](bool on) { g_inplace.store(on); });
+    m.def("current_stream", [](int64_t device) { return reinterpret_cast<int64_t>(c10::hip::getCurrentHIPStream((c10::DeviceIndex)device).stream()); },
+          "the raw handle of the stream the node would launch on (tests compare it with torch's)");
     m.def("epoch_new", &epoch_new);
     m.def("epoch_free", &epoch_free);
     m.attr("abi_version") = FQ_ABI_VERSION;

@@ -569,8 +569,11 @@ class _ThreadState:
         self.cseen = self.cepoch.value if self.cell else 0
 
     def __del__(self):
-        if self.cell and _cnode is not None:
-            _cnode.epoch_free(self.cell)   # (a node that outlives its thread bumps a recycled cell: a spurious forgetting, never a stale hit)
+        try:
+            if self.cell and _cnode is not None:
+                _cnode.epoch_free(self.cell)   # (a node that outlives its thread bumps a recycled cell: a spurious forgetting, never a stale hit)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown: the extension may be gone before the last thread state
+            pass
 
 
 _tls = threading.local()

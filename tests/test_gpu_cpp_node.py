@@ -163,6 +163,10 @@ def test_backward_on_another_stream_and_device_thread(pkg):
     """the node launches on the stream that is current where its backward runs (the engine sets the forward's stream): a forward + backward
     under a side stream, from a second Python thread, equals the default-stream result"""
     from llm_qat_amd import utils_quant as U
+    side = torch.cuda.Stream()
+    for s in (torch.cuda.default_stream(), side):     # the node's notion of "current stream" is torch's
+        with torch.cuda.stream(s):
+            assert U._cnode.current_stream(0) == torch._C._cuda_getCurrentRawStream(0) == s.cuda_stream
     m = mk(U, 512, 128, torch.bfloat16)
     x0 = (torch.randn(64, 512, generator=torch.Generator().manual_seed(7)) * 1.2).cuda().bfloat16()
     want = step(m, x0.clone().requires_grad_(True), False)

@@ -93,3 +93,44 @@ def test_block_step_captured_into_one_graph_matches_eager(autocast):
             assert torch.equal(got[2][n], p.grad), f"replay {trial}: gradient of {n}"
             assert got[2][n][1, 2] == 0, f"replay {trial}: STE mask on {n}"
     llm_qat_amd.reset_learned_state()
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_make_graphed_callables_on_a_block_matches_eager(autocast):
+    """PyTorch's own partial-network capture (torch.cuda.make_graphed_callables: forward and backward of one callable in two graphs, the rest of
+    the step eager) on a fake-quantized block: nothing in the host logic needs the host during a step -- no read-back, no data-dependent
+    launch -- so the block is graphable as it is, and replays give the eager block's bits on fresh data.  (Small models are host-bound:
+    tools/graph_block_bench.py measures 3.3x for configs[0]'s widths.)"""
+    import llm_qat_amd
+    import llm_qat_amd.utils_quant as UQ
+    torch.manual_seed(12)
+    d, m, tokens = 256, 688, 64
+    llm_qat_amd.reset_learned_state()
+    block = Block(UQ, d, m).cuda().bfloat16()
+    with torch.no_grad():
+        for p in block.parameters():
+            p.mul_(0.6)
+            p[1, 2] = 2.5
+    ref = Block(UQ, d, m).cuda().bfloat16()
+    ref.load_state_dict(block.state_dict())
+    sample = torch.randn(2, tokens // 2, d, device="cuda").bfloat16().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast, cache_enabled=False):
+        graphed = torch.cuda.make_graphed_callables(block, (sample,))
+    for trial in range(3):
+        x = (torch.randn(2, tokens // 2, d, device="cuda") * (0.5 + trial)).bfloat16()
+        go = (torch.randn(2, tokens // 2, d, device="cuda") * 1e-2).bfloat16()
+        xs = [x.clone().requires_grad_(True) for _ in range(2)]
+        outs = []
+        for mod, xi in ((graphed, xs[0]), (ref, xs[1])):
+            for p in (block if mod is graphed else ref).parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast, cache_enabled=False):
+                out = mod(xi)
+            out.backward(go)
+            outs.append(out.detach().clone())
+        assert torch.equal(outs[0], outs[1]), f"replay {trial}: output"
+        assert torch.equal(xs[0].grad, xs[1].grad), f"replay {trial}: input gradient"
+        for (n, p), (_, q) in zip(block.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p.grad, q.grad), f"replay {trial}: gradient of {n}"
+            assert p.grad[1, 2] == 0, f"replay {trial}: STE mask on {n}"
+    llm_qat_amd.reset_learned_state()

@@ -232,3 +232,42 @@ def test_checkpointed_block_with_siblings(pkg):
     for impl in ("c++", "python"):
         for reentrant in (False, True):
             assert all(same(a, b) for a, b in zip(res[impl, reentrant], res["eager", reentrant])), (impl, reentrant)
+
+
+def test_module_backward_hooks_and_tied_weights(pkg):
+    """a full backward hook on the module (PyTorch wraps its inputs and outputs in hook nodes around ours), and two modules over ONE Parameter
+    (two nodes, two wgrads accumulated into one .grad by the engine): both nodes == the eager chain"""
+    from llm_qat_amd import utils_quant as U
+    res = {}
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            pkg.cpp_node(impl == "c++")
+        pkg.reset_learned_state()
+        a, b = mk(Q, 128, 128, torch.bfloat16, seed=1), mk(Q, 128, 128, torch.bfloat16, seed=2)
+        b.weight = a.weight                                   # tied
+        seen = []
+        a.register_full_backward_hook(lambda mod, gin, gout: seen.append((gin[0].clone(), gout[0].clone())))
+        x = (torch.randn(3, 7, 128, generator=torch.Generator().manual_seed(11)) * 1.2).cuda().bfloat16().requires_grad_(True)
+        y = b(torch.tanh(a(x))) + a(x * 0.5)
+        y.float().square().sum().backward()
+        res[impl] = [y.detach(), x.grad.clone(), a.weight.grad.clone()] + [t for pair in seen for t in pair]
+    for impl in ("c++", "python"):
+        assert len(res[impl]) == len(res["eager"]) and all(same(p, q) for p, q in zip(res[impl], res["eager"])), impl
+
+
+def test_gradient_accumulation_over_steps(pkg):
+    """.grad that already exists: the engine accumulates the node's (in place masked) weight gradient into it -- three steps without
+    zeroing, both nodes == the eager chain"""
+    from llm_qat_amd import utils_quant as U
+    res = {}
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            pkg.cpp_node(impl == "c++")
+        m = mk(Q, 256, 64, torch.bfloat16)
+        for k in range(3):
+            x = (torch.randn(9, 256, generator=torch.Generator().manual_seed(20 + k)) * 1.2).cuda().bfloat16()
+            m(x).float().square().sum().backward()
+        res[impl] = m.weight.grad.clone()
+    assert same(res["c++"], res["eager"]) and same(res["python"], res["eager"])

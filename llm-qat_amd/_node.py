@@ -55,7 +55,7 @@ def bind(slow_backward):
         return _bound
     lib = _lib.lib()
     addr = lambda name: ctypes.cast(lib[name], ctypes.c_void_p).value  # noqa: E731  (lib[name]: the symbol itself, whatever the attribute holds)
-    _mod.bind(addr("fq_sym_fwd_pair"), addr("fq_ste_bwd_mask_pair"), addr("fq_last_error"), slow_backward)
+    _mod.bind(addr("fq_sym_fwd_pair"), addr("fq_ste_bwd_mask_pair"), addr("fq_sym_fwd_multi"), addr("fq_last_error"), slow_backward)
     _bound = True
     return True
 

@@ -29,14 +29,15 @@ using torch::autograd::variable_list;
 
 decltype(&fq_sym_fwd_pair) g_fwd_pair = nullptr;
 decltype(&fq_ste_bwd_mask_pair) g_bwd_pair = nullptr;
+decltype(&fq_sym_fwd_multi) g_fwd_multi = nullptr;
 decltype(&fq_last_error) g_last_error = nullptr;
 PyObject* g_slow_backward = nullptr;   // utils_quant._pair_backward_from_cpp (leaked on purpose: never released without the GIL)
 std::atomic<bool> g_inplace{true};     // utils_quant._INPLACE_WGRAD
 
 // ---- counters (merged into llm_qat_amd.stats() and into the tests' launch counts) ----------------------------------------------------
-enum Counter { C_FWD_LAUNCH, C_BWD_LAUNCH, C_SLOW_BACKWARD, C_INPLACE_TAKEN, C_REFUSE_UNCALIBRATED, C_REFUSE_CXX_REFS, C_REFUSE_STORAGE,
+enum Counter { C_FWD_LAUNCH, C_FWD_WEIGHT, C_BWD_LAUNCH, C_SLOW_BACKWARD, C_INPLACE_TAKEN, C_REFUSE_UNCALIBRATED, C_REFUSE_CXX_REFS, C_REFUSE_STORAGE,
                C_REFUSE_ANOMALY, C_REFUSE_STORAGE_REFS, C_REFUSE_BASE_REFS, C_COUNT };
-const char* const kCounterNames[C_COUNT] = {"cpp_pair_forward", "cpp_pair_backward", "cpp_slow_backward", "inplace_taken",
+const char* const kCounterNames[C_COUNT] = {"cpp_pair_forward", "cpp_weight_forward", "cpp_pair_backward", "cpp_slow_backward", "inplace_taken",
                                             "inplace_refused:uncalibrated", "inplace_refused:cxx_refs", "inplace_refused:storage",
                                             "inplace_refused:anomaly", "inplace_refused:storage_refs", "inplace_refused:base_refs"};
 std::atomic<int64_t> g_counters[C_COUNT];
@@ -180,8 +181,9 @@ struct FqPairNode : public torch::autograd::Function<FqPairNode> {
 };
 
 // ---- what utils_quant calls ----------------------------------------------------------------------------------------------------------
-void bind(int64_t fwd_pair, int64_t bwd_pair, int64_t last_error, pybind11::object slow_backward) {
+void bind(int64_t fwd_pair, int64_t bwd_pair, int64_t fwd_multi, int64_t last_error, pybind11::object slow_backward) {
     g_fwd_pair = reinterpret_cast<decltype(g_fwd_pair)>(fwd_pair);
+    g_fwd_multi = reinterpret_cast<decltype(g_fwd_multi)>(fwd_multi);
     g_bwd_pair = reinterpret_cast<decltype(g_bwd_pair)>(bwd_pair);
     g_last_error = reinterpret_cast<decltype(g_last_error)>(last_error);
     g_slow_backward = slow_backward.release().ptr();
@@ -240,6 +242,40 @@ pybind11::object pair_forward(const at::Tensor& weight, const at::Tensor& input,
     return pybind11::make_tuple(wq, xq, side_x.defined() ? pybind11::cast(side_x) : pybind11::none());
 }
 
+// A sibling projection whose input another projection has already fake-quantized (q/k/v, gate/up): the weight's own launch (the one-tensor
+// form of the same entry point family) + the node over it and the remembered activation.  -> (wq, xq') or None where the entry point
+// declines the shape (the caller then takes ops.weight_forward's general path).
+pybind11::object weight_forward_node(const at::Tensor& weight, const at::Tensor& input, const at::Tensor& xq, const c10::optional<at::Tensor>& side_x,
+                                     int64_t code, int64_t cols, int64_t rows_w, int64_t rows_x, int64_t mw, int64_t w_bits, bool need_w, bool need_x, bool ac,
+                                     int64_t sem, int64_t epoch) {
+    TORCH_CHECK(g_fwd_multi != nullptr, "llm_qat_amd: _fq_node is not bound to the kernel library");
+    TORCH_CHECK(epoch != 0, "llm_qat_amd: weight_forward_node needs its forward thread's epoch cell");
+    TORCH_CHECK(weight.is_contiguous() && dtype_code(weight.scalar_type()) == code && weight.numel() == rows_w * cols && xq.numel() == rows_x * cols &&
+                    xq.scalar_type() == weight.scalar_type() && weight.device() == xq.device() && (!need_x || side_x.has_value()),
+                "llm_qat_amd: weight_forward_node called with operands its plan does not describe");
+    at::Tensor wq = at::empty_like(weight), side_w;
+    uint8_t* pw = nullptr;
+    if (need_w) {
+        side_w = at::empty({rows_w * 8 + mw}, weight.options().dtype(at::kByte));
+        pw = static_cast<uint8_t*>(side_w.data_ptr());
+    }
+    int rc;
+    {
+        c10::DeviceGuard guard(weight.device());
+        void* stream = c10::hip::getCurrentHIPStream(weight.device().index()).stream();
+        const fq_fwd_tensor t{weight.data_ptr(), wq.data_ptr(), rows_w, (int)w_bits, reinterpret_cast<float*>(pw), pw ? pw + rows_w * 8 : nullptr,
+                              need_w ? (size_t)mw : 0};
+        rc = g_fwd_multi(1, &t, cols, (int)code, (int)sem, ac ? 1 : 0, -2.0f, 2.0f, stream);
+    }
+    if (rc == FQ_ERR_UNSUPPORTED) return pybind11::none();
+    if (rc != FQ_OK) launch_failed("fq_sym_fwd_multi", rc);
+    count(C_FWD_WEIGHT);
+    if (!(need_w || need_x)) return pybind11::make_tuple(wq, xq);
+    PairArgs a{wq, xq, side_w, need_x ? *side_x : at::Tensor(), true, need_w, need_x, rows_w, rows_x, cols, code, epoch};
+    auto out = FqPairNode::apply(weight, input, &a);
+    return pybind11::make_tuple(out[0], out[1]);
+}
+
 // Reference counts of a gradient nobody else holds, learned in this node's own backward (see inplace_ok): utils_quant runs, once at
 // import and on tiny CPU tensors, F.linear over a probe node (-> a view of a temporary) and an elementwise product (-> a plain tensor).
 std::pair<at::Tensor, at::Tensor> probe_node(const at::Tensor& weight, const at::Tensor& input) {
@@ -291,6 +327,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bind", &bind);
     m.def("pair_forward", &pair_forward);
     m.def("pair_node", &pair_node);
+    m.def("weight_forward_node", &weight_forward_node);
     m.def("probe_node", &probe_node);
     m.def("arm_probe", &arm_probe);
     m.def("no_gemm_linear", &no_gemm_linear);

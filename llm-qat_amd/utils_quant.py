@@ -1123,6 +1123,13 @@ class QuantizeLinear(nn.Linear):
                 # remembered data has the pair's shape (mask mode, operand dtype); otherwise the two ordinary nodes
                 if raw.mode not in ("mask", "none") or raw.out.dtype is not weight.dtype:
                     return None
+                if _USE_CNODE:     # the weight's launch and the node in one call into C++
+                    out = _cnode.weight_forward_node(weight, input_, raw.out, raw.saved[0] if need_x else None, pp[0], pp[1], pp[2], pp[3], pp[4], plan[5][0],
+                                                     need_w, need_x, ac, ops._SEM_AUTOCAST if ac else ops._semantics, st.cell)
+                    if out is not None:
+                        _count("act_share_hit")
+                        _count("single_launch")
+                        return out
                 res = ops.weight_forward(weight, self.w_bits, -2.0, 2.0, need_w)
                 if res is None:
                     return None

@@ -174,12 +174,14 @@ class Counter:
     (ops.pair_forward_planned / pair_backward_planned: same launches)"""
     TWINS = {"pair_forward": "pair_forward_planned", "pair_backward": "pair_backward_planned"}
 
-    CPP = {"pair_forward": "cpp_pair_forward", "pair_backward": "cpp_pair_backward"}   # the C++ node's own launches of the same entry points
+    # the C++ node's own launches of the same entry points (a sibling's weight-only launch is one of the three single-tensor forwards in Python)
+    CPP = {"pair_forward": "cpp_pair_forward", "pair_backward": "cpp_pair_backward", "train_forward": "cpp_weight_forward",
+           "sym_forward_autocast": "cpp_weight_forward", "sym_quantize": "cpp_weight_forward"}
 
     def __init__(self, mod, names):
         self.mod, self.n = mod, 0
         self.names = list(names) + [self.TWINS[n] for n in names if n in self.TWINS and hasattr(mod, self.TWINS[n])]
-        self.cpp = [self.CPP[n] for n in names if n in self.CPP]
+        self.cpp = sorted({self.CPP[n] for n in names if n in self.CPP})
 
     def _cpp_counts(self):
         from llm_qat_amd import utils_quant as U

@@ -41,7 +41,8 @@ class LaunchCounter:
         """launches the C++ autograd node made itself (it calls the same two entry points through their addresses)"""
         from llm_qat_amd import utils_quant as U
         c = U._cnode.counters() if U._cnode is not None else {}
-        return {"fq_sym_fwd_pair": c.get("cpp_pair_forward", 0), "fq_ste_bwd_mask_pair": c.get("cpp_pair_backward", 0)}
+        return {"fq_sym_fwd_pair": c.get("cpp_pair_forward", 0), "fq_ste_bwd_mask_pair": c.get("cpp_pair_backward", 0),
+                "fq_sym_fwd_multi": c.get("cpp_weight_forward", 0)}
 
     def __enter__(self):
         self.orig = {}

@@ -48,14 +48,15 @@ def load():
     return mod
 
 
-def bind(slow_backward):
+def bind(slow_backward, slow_backward_one, forget):
     """hand the kernel library's entry points (addresses out of the ctypes binding) and utils_quant's general backward to the node"""
     global _bound
     if _bound or _mod is None:
         return _bound
     lib = _lib.lib()
     addr = lambda name: ctypes.cast(lib[name], ctypes.c_void_p).value  # noqa: E731  (lib[name]: the symbol itself, whatever the attribute holds)
-    _mod.bind(addr("fq_sym_fwd_pair"), addr("fq_ste_bwd_mask_pair"), addr("fq_sym_fwd_multi"), addr("fq_last_error"), slow_backward)
+    _mod.bind(addr("fq_sym_fwd_pair"), addr("fq_ste_bwd_mask_pair"), addr("fq_sym_fwd_multi"), addr("fq_ste_bwd_mask"), addr("fq_ste_bwd_mask_wide"),
+              addr("fq_last_error"), slow_backward, slow_backward_one, forget)
     _bound = True
     return True
 

@@ -30,38 +30,47 @@ using torch::autograd::variable_list;
 decltype(&fq_sym_fwd_pair) g_fwd_pair = nullptr;
 decltype(&fq_ste_bwd_mask_pair) g_bwd_pair = nullptr;
 decltype(&fq_sym_fwd_multi) g_fwd_multi = nullptr;
+decltype(&fq_ste_bwd_mask) g_bwd_one = nullptr;
+decltype(&fq_ste_bwd_mask_wide) g_bwd_wide = nullptr;
 decltype(&fq_last_error) g_last_error = nullptr;
 PyObject* g_slow_backward = nullptr;   // utils_quant._pair_backward_from_cpp (leaked on purpose: never released without the GIL)
+PyObject* g_slow_backward_one = nullptr;   // utils_quant._one_backward_from_cpp
 std::atomic<bool> g_inplace{true};     // utils_quant._INPLACE_WGRAD
 
 // ---- counters (merged into llm_qat_amd.stats() and into the tests' launch counts) ----------------------------------------------------
-enum Counter { C_FWD_LAUNCH, C_FWD_WEIGHT, C_BWD_LAUNCH, C_SLOW_BACKWARD, C_INPLACE_TAKEN, C_REFUSE_UNCALIBRATED, C_REFUSE_CXX_REFS, C_REFUSE_STORAGE,
+enum Counter { C_FWD_LAUNCH, C_FWD_WEIGHT, C_BWD_LAUNCH, C_BWD_ONE, C_BWD_ONE_WIDE, C_SLOW_BACKWARD, C_INPLACE_TAKEN, C_REFUSE_UNCALIBRATED, C_REFUSE_CXX_REFS, C_REFUSE_STORAGE,
                C_REFUSE_ANOMALY, C_REFUSE_STORAGE_REFS, C_REFUSE_BASE_REFS, C_COUNT };
-const char* const kCounterNames[C_COUNT] = {"cpp_pair_forward", "cpp_weight_forward", "cpp_pair_backward", "cpp_slow_backward", "inplace_taken",
+const char* const kCounterNames[C_COUNT] = {"cpp_pair_forward", "cpp_weight_forward", "cpp_pair_backward", "cpp_one_backward", "cpp_one_backward_wide", "cpp_slow_backward", "inplace_taken",
                                             "inplace_refused:uncalibrated", "inplace_refused:cxx_refs", "inplace_refused:storage",
                                             "inplace_refused:anomaly", "inplace_refused:storage_refs", "inplace_refused:base_refs"};
 std::atomic<int64_t> g_counters[C_COUNT];
 inline void count(Counter c) { g_counters[c].fetch_add(1, std::memory_order_relaxed); }
 
 // ---- backward epochs -----------------------------------------------------------------------------------------------------------------
-// utils_quant remembers things per forward thread (a fake-quantized activation for the sibling projections, a pending K/V launch) and
-// must let go of them when a backward over that thread's graph starts.  The Python nodes do that themselves; this node cannot touch
-// Python state without the GIL, so it bumps a counter that utils_quant compares on its next look-up (what was stored under an older
-// epoch is stale).  One cell per forward thread state, recycled: a bump that reaches a recycled cell only invalidates, which is safe.
+// utils_quant remembers things per forward thread (a fake-quantized activation for the sibling projections, a pending V of the K/V hooks)
+// and must let go of them when a backward over that thread's graph starts.  The Python nodes do that themselves; these nodes cannot touch
+// Python state without the GIL, so a backward bumps a counter cell that utils_quant compares on the thread's next call (`_state()`): what
+// was remembered under an older epoch goes then.  One exception is worth the GIL: a PENDING V RESULT NOBODY ASKED FOR (a wrong guess of
+// the K/V speculation, once per call signature) pins a tensor and its side buffer -- the thread raises the cell's second word while one is
+// pending, and the first backward that sees it calls utils_quant._forget_from_cpp under the GIL.  One cell (two words) per forward thread
+// state, recycled: a bump that reaches a recycled cell only invalidates, which is safe.
+struct Cell { std::atomic<int64_t> epoch{0}, pending{0}; };
 struct Cells {
     std::mutex m;
-    std::deque<std::atomic<int64_t>> cells;   // (a deque never moves its elements)
-    std::vector<std::atomic<int64_t>*> free;
+    std::deque<Cell> cells;   // (a deque never moves its elements)
+    std::vector<Cell*> free;
 } g_cells;
+PyObject* g_forget = nullptr;   // utils_quant._forget_from_cpp(cell handle)
 
 int64_t epoch_new() {
     std::lock_guard<std::mutex> lock(g_cells.m);
-    std::atomic<int64_t>* c;
+    Cell* c;
     if (!g_cells.free.empty()) {
         c = g_cells.free.back();
         g_cells.free.pop_back();
+        c->pending.store(0);
     } else {
-        g_cells.cells.emplace_back(0);
+        g_cells.cells.emplace_back();
         c = &g_cells.cells.back();
     }
     return reinterpret_cast<int64_t>(c);
@@ -69,7 +78,16 @@ int64_t epoch_new() {
 
 void epoch_free(int64_t h) {
     std::lock_guard<std::mutex> lock(g_cells.m);
-    g_cells.free.push_back(reinterpret_cast<std::atomic<int64_t>*>(h));
+    g_cells.free.push_back(reinterpret_cast<Cell*>(h));
+}
+
+inline void backward_began(int64_t h) {
+    Cell* c = reinterpret_cast<Cell*>(h);
+    c->epoch.fetch_add(1, std::memory_order_release);
+    if (c->pending.load(std::memory_order_relaxed) != 0 && c->pending.exchange(0) != 0 && g_forget != nullptr) {
+        pybind11::gil_scoped_acquire gil;
+        pybind11::reinterpret_borrow<pybind11::object>(g_forget)(h);
+    }
 }
 
 // ---- the in-place guard (utils_quant._inplace_ok, on C++ reference counts) -------------------------------------------------------------
@@ -143,7 +161,7 @@ struct FqPairNode : public torch::autograd::Function<FqPairNode> {
             }
             return {grads[0], grads[1], at::Tensor()};
         }
-        reinterpret_cast<std::atomic<int64_t>*>(m[5])->fetch_add(1, std::memory_order_release);
+        backward_began(m[5]);
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &gw = grads[0], &gx = grads[1], &side_w = saved[0], &side_x = saved[1];
         if (gw.defined() && gx.defined() && side_w.defined() && side_x.defined() && gw.is_cuda() && gx.is_cuda() && gw.scalar_type() == dtype &&
@@ -180,8 +198,77 @@ struct FqPairNode : public torch::autograd::Function<FqPairNode> {
     }
 };
 
+// ---- the one-tensor node ---------------------------------------------------------------------------------------------------------------
+// utils_quant._PrecomputedAct in C++: a node over ONE tensor that a launch has already fake-quantized (K and V of the KV-cache hooks,
+// models/modeling_llama_quant.py:320-327, which share a forward launch but never a node).  Forward launches nothing; backward is that
+// tensor's own STE launch -- fq_ste_bwd_mask, or fq_ste_bwd_mask_wide behind the reference's fp32 result under autocast (fp32 gradient in,
+// input-dtype gradient out).  Never in place: these are gradients of tensors a caller can see.
+struct OneArgs {
+    at::Tensor y, side;
+    int64_t rows, cols, epoch;
+    double lo, hi;
+};
+
+struct FqOneNode : public torch::autograd::Function<FqOneNode> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const OneArgs* a) {
+        ctx->set_materialize_grads(false);
+        ctx->save_for_backward({a->side});
+        ctx->saved_data["m"] = std::vector<int64_t>{a->rows, a->cols, (int64_t)x.scalar_type(), a->epoch, (int64_t)(a->y.scalar_type() != x.scalar_type())};
+        ctx->saved_data["c"] = std::vector<double>{a->lo, a->hi};
+        return a->y.view_as(a->y);
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const at::Tensor& g = grads[0];
+        if (!g.defined()) return {at::Tensor(), at::Tensor()};
+        const auto m = ctx->saved_data["m"].toIntVector();
+        const auto c = ctx->saved_data["c"].toDoubleVector();
+        const int64_t rows = m[0], cols = m[1];
+        const auto dtype = (c10::ScalarType)m[2];
+        const bool wide = m[4] != 0;
+        backward_began(m[3]);
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor& side = saved[0];
+        const int code = dtype_code(dtype);
+        if (side.defined() && g.is_cuda() && code >= 0 && g.scalar_type() == (wide ? at::kFloat : dtype) && !at::GradMode::is_enabled() && g.is_contiguous() &&
+            g.numel() == rows * cols && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15) == 0) {
+            at::Tensor gx = at::empty(g.sizes(), g.options().dtype(dtype));
+            auto* sp = static_cast<uint8_t*>(side.data_ptr());
+            c10::DeviceGuard guard(g.device());
+            void* stream = c10::hip::getCurrentHIPStream(g.device().index()).stream();
+            const int rc = wide ? g_bwd_wide(g.data_ptr(), gx.data_ptr(), rows, reinterpret_cast<const float*>(sp), sp + rows * 8, nullptr, nullptr, 0, nullptr,
+                                             nullptr, cols, (float)c[0], (float)c[1], code, stream)
+                                : g_bwd_one(g.data_ptr(), gx.data_ptr(), rows, cols, (float)c[0], (float)c[1], reinterpret_cast<const float*>(sp), sp + rows * 8,
+                                            (size_t)(side.numel() - rows * 8), code, stream);
+            if (rc == FQ_OK) {
+                count(wide ? C_BWD_ONE_WIDE : C_BWD_ONE);
+                return {gx, at::Tensor()};
+            }
+            if (rc != FQ_ERR_UNSUPPORTED) launch_failed(wide ? "fq_ste_bwd_mask_wide" : "fq_ste_bwd_mask", rc);
+        }
+        count(C_SLOW_BACKWARD);
+        pybind11::gil_scoped_acquire gil;
+        pybind11::object out = pybind11::reinterpret_borrow<pybind11::object>(g_slow_backward_one)(
+            pybind11::cast(g), side.defined() ? pybind11::cast(side) : pybind11::none(), rows, cols, c[0], c[1], (int64_t)code, wide);
+        variable_list res(2);
+        if (!out.is_none()) res[0] = out.cast<at::Tensor>();
+        return res;
+    }
+};
+
+at::Tensor one_node(const at::Tensor& x, const at::Tensor& y, const at::Tensor& side, int64_t rows, int64_t cols, double lo, double hi, int64_t epoch) {
+    TORCH_CHECK(epoch != 0, "llm_qat_amd: one_node needs its forward thread's epoch cell");
+    OneArgs a{y, side, rows, cols, epoch, lo, hi};
+    return FqOneNode::apply(x, &a);
+}
+
 // ---- what utils_quant calls ----------------------------------------------------------------------------------------------------------
-void bind(int64_t fwd_pair, int64_t bwd_pair, int64_t fwd_multi, int64_t last_error, pybind11::object slow_backward) {
+void bind(int64_t fwd_pair, int64_t bwd_pair, int64_t fwd_multi, int64_t bwd_one, int64_t bwd_wide, int64_t last_error, pybind11::object slow_backward,
+          pybind11::object slow_backward_one, pybind11::object forget) {
+    g_forget = forget.release().ptr();
+    g_bwd_one = reinterpret_cast<decltype(g_bwd_one)>(bwd_one);
+    g_bwd_wide = reinterpret_cast<decltype(g_bwd_wide)>(bwd_wide);
+    g_slow_backward_one = slow_backward_one.release().ptr();
     g_fwd_pair = reinterpret_cast<decltype(g_fwd_pair)>(fwd_pair);
     g_fwd_multi = reinterpret_cast<decltype(g_fwd_multi)>(fwd_multi);
     g_bwd_pair = reinterpret_cast<decltype(g_bwd_pair)>(bwd_pair);
@@ -327,6 +414,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bind", &bind);
     m.def("pair_forward", &pair_forward);
     m.def("pair_node", &pair_node);
+    m.def("one_node", &one_node);
     m.def("weight_forward_node", &weight_forward_node);
     m.def("probe_node", &probe_node);
     m.def("arm_probe", &arm_probe);

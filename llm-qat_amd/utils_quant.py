@@ -104,9 +104,10 @@ def stats(reset=False):
                                          leans on is missing in this build (fail closed; warned once)
       w12_fused_unverified               1-/2-bit weights that took ATen's own abs + mean because the one-launch kernel's restatement of
                                          ATen's summation order did not verify on this device / torch build
-      cpp_pair_forward / cpp_pair_backward / cpp_slow_backward
-                                         QuantizeLinear operand pairs served by the C++ autograd node (_fq_node.so; `host_node()` says whether
-                                         it is loaded): launches made from C++, and backwards it handed back to the Python node's code"""
+      cpp_pair_forward / cpp_weight_forward / cpp_pair_backward / cpp_one_backward / cpp_slow_backward
+                                         what the C++ autograd nodes did (_fq_node.so; `host_node()` says whether it is loaded): operand-pair and
+                                         weight-only launches made from C++, pair / one-tensor (K, V) backwards, and backwards handed back to the
+                                         Python nodes' code"""
     out = dict(_stats)
     if reset:
         _stats.clear()
@@ -554,22 +555,38 @@ class _ThreadState:
     """Everything the host logic remembers between calls, per FORWARD thread (thread-local: it dies with its thread, so a short-lived
     evaluation or DataParallel replica thread leaves nothing behind).  A backward runs on the autograd engine's threads: its nodes carry
     a weak reference to the state of the thread whose forward built them (`ctx.fq_st`), which is how `_backward_started` reaches it."""
-    __slots__ = ("acts", "outs", "kv", "epoch", "ref", "cell", "cepoch", "cseen", "__weakref__")
+    __slots__ = ("acts", "outs", "_kv", "epoch", "ref", "cell", "cepoch", "cpending", "cseen", "__weakref__")
 
     def __init__(self):
         self.acts = {}        # key -> (weakref(input), its version, its address, _Raw, the result's version, needs grad, region, stream)
         self.outs = []        # the last few QuantizeLinear outputs of this thread, in order (weakly): what the KV hooks pair
-        self.kv = None        # the pending half of a K + V launch
+        self._kv = None       # the pending half of a K + V launch (`kv`: the property below tells the C++ nodes when one is pending)
         self.epoch = 0        # fake-quant backward passes started on graphs this thread built
         self.ref = weakref.ref(self)
         # the C++ node cannot touch this object from the engine's thread: its backward bumps a counter cell instead, and `_state()` --
         # the first thing every forward call does -- notices and lets go then (the same forgetting, at the thread's next look-up)
         self.cell = _cnode.epoch_new() if _cnode is not None else 0
         self.cepoch = ctypes.c_int64.from_address(self.cell) if self.cell else None
+        self.cpending = ctypes.c_int64.from_address(self.cell + 8) if self.cell else None
         self.cseen = self.cepoch.value if self.cell else 0
+        if self.cell:
+            _cell_states[self.cell] = self.ref
+
+    @property
+    def kv(self):
+        return self._kv
+
+    @kv.setter
+    def kv(self, value):
+        # a pending V result pins a tensor + its side buffer: the one thing a C++ node's backward takes the GIL for (csrc/fq_autograd_node.cpp)
+        self._kv = value
+        if self.cpending is not None:
+            self.cpending.value = 0 if value is None else 1
 
     def __del__(self):
         try:
+            if self.cell:
+                _cell_states.pop(self.cell, None)
             if self.cell and _cnode is not None:
                 _cnode.epoch_free(self.cell)   # (a node that outlives its thread bumps a recycled cell: a spurious forgetting, never a stale hit)
         except Exception:  # noqa: BLE001 -- interpreter shutdown: the extension may be gone before the last thread state
@@ -577,6 +594,16 @@ class _ThreadState:
 
 
 _tls = threading.local()
+_cell_states = {}      # epoch cell -> weakref(_ThreadState): how a C++ node's backward reaches the forward thread's state (_forget_from_cpp)
+
+
+def _forget_from_cpp(cell):
+    """called by a C++ node's backward, under the GIL, when its forward thread has a V result pending that nobody asked for"""
+    ref = _cell_states.get(cell)
+    st = ref() if ref is not None else None
+    if st is not None:
+        st.cseen = st.cepoch.value
+        _forget(st)
 
 
 def _state():
@@ -816,8 +843,8 @@ def quantize_kv(key_states, value_states, clip_val_k, clip_val_v, num_bits):
         res = ops.pair_forward(k, v, num_bits, num_bits, lo, hi, need_k, need_v, wide=True)
         if res is not None:
             kq, vq, side_k, side_v, rows_k, rows_v, cols = res
-            return (_PrecomputedAct.apply(k, kq, side_k, rows_k, cols, (lo, hi)) if need_k else kq,
-                    _PrecomputedAct.apply(v, vq, side_v, rows_v, cols, (lo, hi)) if need_v else vq)
+            return (_precomputed(k, kq, side_k, rows_k, cols, (lo, hi)) if need_k else kq,
+                    _precomputed(v, vq, side_v, rows_v, cols, (lo, hi)) if need_v else vq)
     return (SymQuantizer.apply(k, clip_val_k, num_bits, False), SymQuantizer.apply(v, clip_val_v, num_bits, False))
 
 
@@ -891,7 +918,7 @@ def _kv_hook(x, clip_val, num_bits):
             st.kv = None
             _count("kv_pair_hit")
             vq, side_v, rows_v, cols, clip = vres   # V: quantized together with K a moment ago; its autograd node is built only now
-            return vq if side_v is None else _PrecomputedAct.apply(x, vq, side_v, rows_v, cols, clip)
+            return vq if side_v is None else _precomputed(x, vq, side_v, rows_v, cols, clip)
         _kv_discard(st)
     rec = st.outs
     if not rec:
@@ -925,7 +952,7 @@ def _kv_hook(x, clip_val, num_bits):
             # reference leaves None: tests/test_gpu_random_programs.py).  Each of K and V gets its own node over its own side buffer.
             kq, vq, side_k, side_v, rows_k, rows_v, cols = res
             st.kv = (weakref.ref(v), v._version, (vq, side_v if need else None, rows_v, cols, (lo, hi)), _kv_state(st, clip_val, num_bits, stream), sig)
-            return _PrecomputedAct.apply(x, kq, side_k, rows_k, cols, (lo, hi)) if need else kq
+            return _precomputed(x, kq, side_k, rows_k, cols, (lo, hi)) if need else kq
     return None
 
 
@@ -1011,6 +1038,25 @@ class _PrecomputedAct(torch.autograd.Function):
             return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.dtype), None, None, None, None, None
         g = grad_output if grad_output.dtype == ctx.dtype else grad_output.to(ctx.dtype)
         return ops.train_backward(g, side, rows, cols, lo, hi), None, None, None, None, None
+
+
+class _CppCtx1:
+    """what _PrecomputedAct.backward reads from its ctx, for a backward the C++ one-tensor node hands back"""
+    __slots__ = ("rows_cols", "clip", "dtype", "fq_st", "wide", "saved_tensors")
+
+
+def _one_backward_from_cpp(g, side, rows, cols, lo, hi, code, wide):
+    """the C++ one-tensor node's way out of its straight line (another gradient dtype, create_graph, strided or unaligned gradients)"""
+    ctx = _CppCtx1()
+    ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_st, ctx.wide, ctx.saved_tensors = (rows, cols), (lo, hi), _CODE_DTYPE[code], None, wide, (side,)
+    return _PrecomputedAct.backward(ctx, g)[0]
+
+
+def _precomputed(x, y, side, rows, cols, clip):
+    """a node of x's own over a result some launch has already produced: the C++ one (csrc/fq_autograd_node.cpp::FqOneNode) or _PrecomputedAct"""
+    if _USE_CNODE and x.is_cuda:
+        return _cnode.one_node(x, y, side, rows, cols, clip[0], clip[1], _state().cell)
+    return _PrecomputedAct.apply(x, y, side, rows, cols, clip)
 
 
 class QuantizeLinear(nn.Linear):
@@ -1211,7 +1257,7 @@ class QuantizeLinear(nn.Linear):
             self._fq_wcache = (wkey, cached)
             _count("wcache_fill")
             wq = _ReuseQuantizedWeight.apply(weight, cached, _CLIP) if need_w else res[0]
-            xq = _PrecomputedAct.apply(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if need_x else res[1]
+            xq = _precomputed(input_, res[1], side_x, rows_x, cols, (-2.0, 2.0)) if need_x else res[1]
             return wq, xq
         if need_w or need_x:
             return _PairNode.apply(weight, input_, res, code, share)
@@ -1297,7 +1343,7 @@ def _calibrate_cnode():
     if "view" not in base or "plain" not in base:
         raise RuntimeError(f"reference-count baselines incomplete: {base}")
     _cnode.set_inplace(_INPLACE_WGRAD)
-    if not _node.bind(_pair_backward_from_cpp):
+    if not _node.bind(_pair_backward_from_cpp, _one_backward_from_cpp, _forget_from_cpp):
         raise RuntimeError("could not bind the node to the kernel library")
     _cnode_ready = True
     _USE_CNODE = True

@@ -271,3 +271,44 @@ def test_gradient_accumulation_over_steps(pkg):
             m(x).float().square().sum().backward()
         res[impl] = m.weight.grad.clone()
     assert same(res["c++"], res["eager"]) and same(res["python"], res["eager"])
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_kv_hooks_through_the_one_tensor_node(pkg, autocast):
+    """k_proj, v_proj and the two unchanged KV hooks (modeling_llama_quant.py:317-327): one forward launch for K and V, one node EACH -- the
+    C++ one-tensor node (fp32 gradients in under autocast: the wide backward) or _PrecomputedAct -- == the eager chain; incl. a backward that
+    is itself recorded (handed back to the Python node's code)"""
+    from llm_qat_amd import utils_quant as U
+    res = {}
+    clip = torch.tensor([-2.0, 2.0])
+    for impl in ("eager", "c++", "python"):
+        Q = TL.EagerQuant() if impl == "eager" else U
+        if impl != "eager":
+            pkg.cpp_node(impl == "c++")
+        pkg.reset_learned_state()
+        kp, vp = mk(Q, 128, 128, torch.bfloat16, seed=4), mk(Q, 128, 128, torch.bfloat16, seed=5)
+        x = (torch.randn(2, 11, 128, generator=torch.Generator().manual_seed(13)) * 1.5).cuda().bfloat16().requires_grad_(True)
+        pkg.stats(reset=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            k, v = kp(x), vp(x)
+            k = Q.SymQuantizer.apply(k, clip, 4, False)
+            v = Q.SymQuantizer.apply(v, clip, 4, False)
+        (k.float().square().sum() + 2 * v.float().sum()).backward()
+        st = pkg.stats(reset=True)
+        if impl == "c++":
+            # (V's gradient is sum()'s expanded, stride-0 tensor: under autocast it reaches the node as it is -- outside the straight line, so
+            # the Python code's strided path serves it; K's contiguous gradient takes the C++ launch)
+            fast = st.get("cpp_one_backward_wide" if autocast else "cpp_one_backward", 0)
+            assert st.get("kv_pair_hit") == 1 and fast >= 1 and fast + st.get("cpp_slow_backward", 0) == 2, st
+        if impl == "python":
+            assert not any(k_.startswith("cpp_") for k_ in st), st
+        res[impl] = [k.detach(), v.detach(), x.grad.clone(), kp.weight.grad.clone(), vp.weight.grad.clone()]
+        # create_graph through the hooks
+        x2 = x.detach().clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            k2 = Q.SymQuantizer.apply(kp(x2), clip, 4, False)
+        gx, = torch.autograd.grad(k2.float().square().sum(), [x2], create_graph=True)
+        ggx, = torch.autograd.grad(gx.float().square().sum(), [x2], allow_unused=True)
+        res[impl] += [gx.detach(), ggx]
+    for impl in ("c++", "python"):
+        assert all(same(p, q) for p, q in zip(res[impl], res["eager"])), (impl, autocast)

@@ -176,7 +176,8 @@ class Counter:
 
     # the C++ node's own launches of the same entry points (a sibling's weight-only launch is one of the three single-tensor forwards in Python)
     CPP = {"pair_forward": "cpp_pair_forward", "pair_backward": "cpp_pair_backward", "train_forward": "cpp_weight_forward",
-           "sym_forward_autocast": "cpp_weight_forward", "sym_quantize": "cpp_weight_forward"}
+           "sym_forward_autocast": "cpp_weight_forward", "sym_quantize": "cpp_weight_forward", "train_backward": "cpp_one_backward",
+           "train_backward_wide": "cpp_one_backward_wide"}
 
     def __init__(self, mod, names):
         self.mod, self.n = mod, 0

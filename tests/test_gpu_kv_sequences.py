@@ -14,6 +14,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiny_llama as TL  # noqa: E402
 
 
+@pytest.fixture(autouse=True, params=["c++", "python"])
+def node(request):
+    """every test of this file with either kind of autograd node behind K and V (csrc/fq_autograd_node.cpp::FqOneNode / _PrecomputedAct)"""
+    import llm_qat_amd
+    assert llm_qat_amd.cpp_node(request.param == "c++") == (request.param == "c++"), llm_qat_amd.host_node()
+    yield request.param
+    llm_qat_amd.cpp_node(True)
+
+
 def same(a, b):
     return len(a) == len(b) and all((x is None and y is None) or (x is not None and y is not None and x.dtype == y.dtype and x.shape == y.shape
                                                                     and torch.equal(x.nan_to_num(), y.nan_to_num())) for x, y in zip(a, b))

@@ -42,7 +42,8 @@ class LaunchCounter:
         from llm_qat_amd import utils_quant as U
         c = U._cnode.counters() if U._cnode is not None else {}
         return {"fq_sym_fwd_pair": c.get("cpp_pair_forward", 0), "fq_ste_bwd_mask_pair": c.get("cpp_pair_backward", 0),
-                "fq_sym_fwd_multi": c.get("cpp_weight_forward", 0)}
+                "fq_sym_fwd_multi": c.get("cpp_weight_forward", 0), "fq_ste_bwd_mask": c.get("cpp_one_backward", 0),
+                "fq_ste_bwd_mask_wide": c.get("cpp_one_backward_wide", 0)}
 
     def __enter__(self):
         self.orig = {}

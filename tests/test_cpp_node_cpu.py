@@ -77,3 +77,22 @@ def test_probe_node_passes_gradients_through():
     torch.nn.functional.linear(xr, wr).square().sum().backward()
     assert torch.equal(w.grad, wr.grad) and torch.equal(x.grad, xr.grad)
     assert U._cnode.baselines() == before        # (an unarmed probe records nothing)
+
+
+def test_a_pending_v_result_raises_the_cells_second_word():
+    """the one thing a C++ node's backward takes the GIL for: a V result of the K/V speculation that is still pending when a backward
+    starts.  The thread raises the flag while one is pending; `_forget_from_cpp(cell)` -- what the node calls -- drops it and counts it."""
+    import llm_qat_amd
+    from llm_qat_amd import utils_quant as U
+    st = U._state()
+    assert st.cpending is not None and st.cpending.value == 0
+    llm_qat_amd.stats(reset=True)
+    st.kv = (None, 0, None, None, ("a call signature",))
+    assert st.cpending.value == 1
+    st.acts = {"k": "remembered"}
+    U._forget_from_cpp(st.cell)
+    assert st.kv is None and st.cpending.value == 0 and not st.acts
+    assert llm_qat_amd.stats().get("kv_pair_discarded") == 1
+    assert U._state() is st and st.cseen == st.cepoch.value      # nothing left for the lazy path to do
+    llm_qat_amd.reset_learned_state()
+    U._forget_from_cpp(12345)                                    # a cell no live thread state owns: ignored

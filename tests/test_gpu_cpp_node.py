@@ -312,3 +312,34 @@ def test_kv_hooks_through_the_one_tensor_node(pkg, autocast):
         res[impl] += [gx.detach(), ggx]
     for impl in ("c++", "python"):
         assert all(same(p, q) for p, q in zip(res[impl], res["eager"])), (impl, autocast)
+
+
+def test_no_growth_over_many_steps(pkg):
+    """2 000 block steps through the C++ nodes: device memory, host memory and the number of live tensors are where they were after the first
+    hundred (nothing the nodes, the epoch cells or the pending-V flag hold outlives its step)"""
+    import gc
+    import resource
+    from llm_qat_amd import utils_quant as U
+    from test_gpu_graph_block import Block, _step
+    torch.manual_seed(0)
+    block = Block(U, 128, 256).cuda().bfloat16()
+    x = torch.randn(1, 32, 128, device="cuda").bfloat16().requires_grad_(True)
+    go = (torch.randn(1, 32, 128, device="cuda") * 1e-2).bfloat16()
+
+    def run(n):
+        for _ in range(n):
+            block.zero_grad(set_to_none=True)
+            x.grad = None
+            _step(block, x, go, True)
+        torch.cuda.synchronize()
+        gc.collect()
+        return torch.cuda.memory_allocated(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss, sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor))
+
+    run(100)
+    dev0, rss0, n0 = run(100)
+    dev1, rss1, n1 = run(2000)
+    assert dev1 == dev0, (dev0, dev1)
+    assert n1 <= n0 + 2, (n0, n1)
+    assert rss1 - rss0 < 32 * 1024, f"host memory grew by {(rss1 - rss0) / 1024:.1f} MiB over 2 000 steps"     # ru_maxrss is in KiB
+    st = pkg.stats()
+    assert st.get("cpp_pair_backward", 0) >= 7 * 2000 and st.get("cpp_one_backward_wide", 0) >= 2 * 2000, st

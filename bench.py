@@ -673,7 +673,7 @@ def gpu_eager(wl, iters=5, autocast=False):
                     + (", inside torch.autocast(cuda, bf16) as LLM-QAT trains (fp32 intermediates, fp32 outputs)" if autocast else "")}
 
 
-def autograd_path(wl, iters=40):
+def autograd_path(wl, iters=200):
     """The same step through the product's autograd Functions (SymQuantizer.apply + .backward on the step's own tensors):
     allocator, Python, ctypes and autograd-engine cost included -- what a training loop pays per call."""
     import torch
@@ -690,7 +690,7 @@ def autograd_path(wl, iters=40):
         ya = SymQuantizer.apply(a, clip, 8, False)
         torch.autograd.backward([yw, ya], [gw, ga])
 
-    for k in range(3):
+    for k in range(20):
         one(k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -727,7 +727,7 @@ def self_check(out):
     return res
 
 
-def api_path(wl, iters=60):
+def api_path(wl, iters=200):
     """What the module API delivers on the metric tensors: QuantizeLinear(11008 -> 4096, W4 A8).forward + .backward through the real
     module code (operand pairing: ONE forward launch; _PairNode: one backward launch with the weight's gradient masked in place behind
     its guard; activation cache, autograd, allocator, Python all included) -- with the GEMM taken out: F.linear is replaced, for this
@@ -776,7 +776,7 @@ def api_path(wl, iters=60):
             m, a = mods[k % len(mods)]
             m.weight.grad = a.grad = None
             m(a).backward(go)
-        for k in range(8):
+        for k in range(20):
             one(k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -215,7 +215,7 @@ struct FqOneNode : public torch::autograd::Function<FqOneNode> {
         ctx->save_for_backward({a->side});
         ctx->saved_data["m"] = std::vector<int64_t>{a->rows, a->cols, (int64_t)x.scalar_type(), a->epoch, (int64_t)(a->y.scalar_type() != x.scalar_type())};
         ctx->saved_data["c"] = std::vector<double>{a->lo, a->hi};
-        return a->y.view_as(a->y);
+        return a->y;   // the launch's own fresh result (not an input of this node): it becomes the node's output as it is, as in the reference
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {

@@ -257,6 +257,23 @@ class _FakeQuantFunction(torch.autograd.Function):
         return grad_input, None, None, None
 
 
+def _apply_over_raw(kind, input, clip_val, num_bits, layerwise):
+    """SymQuantizer.apply / AsymQuantizer.apply for the ordinary training call -- a CUDA input that needs a gradient, a clip that does not,
+    mask backward -- with the C++ one-tensor node behind the result (no Python on the engine's thread in its backward).  Same launch, same
+    saved side buffer, same values as `_FakeQuantFunction`; anything else returns None and the Function itself serves."""
+    if not (isinstance(input, torch.Tensor) and input.is_cuda and input.requires_grad and torch.is_grad_enabled() and _BACKWARD_MODE == "mask"
+            and isinstance(clip_val, torch.Tensor) and not clip_val.requires_grad and input.dtype is not torch.float64)\
+            or torch.compiler.is_compiling() or _functorch_active is None or _functorch_active():
+        return None
+    if type(num_bits) is not int:
+        num_bits = ops.bits_arg(num_bits)
+    raw = _compute(kind, input, clip_val, num_bits, layerwise, False, True)
+    if raw.mode in ("mask", "mask_wide"):
+        rows, cols = raw.rows_cols
+        return _cnode.one_node(input, raw.out, raw.saved[0], rows, cols, raw.clip[0], raw.clip[1], _state().cell)
+    return _SharedAct.apply(input, raw, True)     # (bounds / plain data flows: the Python node over the same result)
+
+
 class SymQuantizer(_FakeQuantFunction):
     """uniform symmetric (absmax) fake quantization; straight-through gradient masked to clip_val"""
 
@@ -269,6 +286,10 @@ class SymQuantizer(_FakeQuantFunction):
         # the unchanged KV-cache hooks (two consecutive apply calls on k_proj's and v_proj's outputs): one launch, see point 7
         if _PAIR_KV and cls is SymQuantizer and not layerwise and type(num_bits) is int:
             out = _kv_hook(input, clip_val, num_bits)
+            if out is not None:
+                return out
+        if _USE_CNODE and cls is SymQuantizer:
+            out = _apply_over_raw("sym", input, clip_val, num_bits, layerwise)
             if out is not None:
                 return out
         return super().apply(input, clip_val, num_bits, layerwise)
@@ -298,6 +319,14 @@ class AsymQuantizer(_FakeQuantFunction):
     @staticmethod
     def forward(ctx, input, clip_val, num_bits, layerwise):
         return _FakeQuantFunction._fwd("asym", ctx, input, clip_val, num_bits, layerwise)
+
+    @classmethod
+    def apply(cls, input, clip_val, num_bits, layerwise):
+        if _USE_CNODE and cls is AsymQuantizer:
+            out = _apply_over_raw("asym", input, clip_val, num_bits, layerwise)
+            if out is not None:
+                return out
+        return super().apply(input, clip_val, num_bits, layerwise)
 
 
 class _LowBitWeightCpu(torch.autograd.Function):
@@ -700,8 +729,10 @@ class _SharedAct(torch.autograd.Function):
     backward is the ordinary STE backward of `_FakeQuantFunction` over the raw's side buffer."""
 
     @staticmethod
-    def forward(ctx, x, raw):
+    def forward(ctx, x, raw, own=False):
         _attach(ctx, raw)
+        if own:               # the raw is this call's alone (_apply_over_raw): its tensor becomes the output as it is
+            return raw.out
         return raw.out.view_as(raw.out)   # a tensor of this node's own: the raw stays plain data for the next sibling
 
     backward = _FakeQuantFunction.backward
@@ -1018,26 +1049,27 @@ class _PrecomputedAct(torch.autograd.Function):
     y may be the reference's fp32 result under autocast (then fp32 gradients come back: the wide backward)."""
 
     @staticmethod
-    def forward(ctx, x, y, side, rows, cols, clip):
-        ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_st = (rows, cols), clip, x.dtype, _state().ref
+    def forward(ctx, x, res, rows, cols, clip):
+        y, side = res     # (inside a tuple: not inputs of this node -- y is the launch's fresh result and becomes the output as it is, so that
+        ctx.rows_cols, ctx.clip, ctx.dtype, ctx.fq_st = (rows, cols), clip, x.dtype, _state().ref     # in-place ops on it work as in the reference)
         ctx.wide = y.dtype != x.dtype
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(side)
-        return y.view_as(y)
+        return y
 
     @staticmethod
     @_graph_aware
     def backward(ctx, grad_output):
         if grad_output is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None
         _backward_started(ctx.fq_st)
         (side,) = ctx.saved_tensors
         lo, hi = ctx.clip
         rows, cols = ctx.rows_cols
         if ctx.wide:
-            return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.dtype), None, None, None, None, None
+            return ops.train_backward_wide(grad_output, side, rows, cols, lo, hi, ctx.dtype), None, None, None, None
         g = grad_output if grad_output.dtype == ctx.dtype else grad_output.to(ctx.dtype)
-        return ops.train_backward(g, side, rows, cols, lo, hi), None, None, None, None, None
+        return ops.train_backward(g, side, rows, cols, lo, hi), None, None, None, None
 
 
 class _CppCtx1:
@@ -1056,7 +1088,7 @@ def _precomputed(x, y, side, rows, cols, clip):
     """a node of x's own over a result some launch has already produced: the C++ one (csrc/fq_autograd_node.cpp::FqOneNode) or _PrecomputedAct"""
     if _USE_CNODE and x.is_cuda:
         return _cnode.one_node(x, y, side, rows, cols, clip[0], clip[1], _state().cell)
-    return _PrecomputedAct.apply(x, y, side, rows, cols, clip)
+    return _PrecomputedAct.apply(x, (y, side), rows, cols, clip)
 
 
 class QuantizeLinear(nn.Linear):

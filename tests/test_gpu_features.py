@@ -1090,6 +1090,7 @@ def test_checkpoint_drops_first_pass_side_buffers(pkg, reentrant):
     from llm_qat_amd.utils_quant import SymQuantizer
     clip = torch.tensor([-2.0, 2.0])
     rows, cols = 2048, 4096
+    pkg.reset_learned_state()      # (what an earlier test's last forward left remembered would be let go of inside the measured region)
     x = (torch.randn(rows, cols, device="cuda") * 1.2).bfloat16().requires_grad_(True)
 
     def block(t):

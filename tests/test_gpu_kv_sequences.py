@@ -135,6 +135,19 @@ def v_inplace(Q, ac):
     return finish([k, v], mods[:2], x)
 
 
+def results_modified_in_place(Q, ac):
+    """the reference's hook results are fresh tensors of their Functions: in-place arithmetic on them (here a scale and a shift) is ordinary
+    autograd -- the drop-in's K and V results are the launch's own tensors too, not views handed out by a node (round 5)"""
+    mods, x = build(Q)
+    with _ctx(ac):
+        k, v = mods[0](x), mods[1](x)
+        k = Q.SymQuantizer.apply(k, C(), 4, False)
+        v = Q.SymQuantizer.apply(v, C(), 4, False)
+        k.mul_(0.5)
+        v.add_(0.25)
+    return finish([k, v], mods[:2], x)
+
+
 def nograd_hooks(Q, ac):
     mods, x = build(Q)
     with _ctx(ac), torch.no_grad():
@@ -148,7 +161,8 @@ def nograd_hooks(Q, ac):
 SCENARIOS = {"V before K": (v_before_k, (0, 0, 0)), "K twice, then V": (k_twice, (1, 0, 1)), "different clips": (diff_clip, (1, 0, 1)),
              "K 4-bit, V 8-bit": (diff_bits, (1, 0, 1)), "two blocks interleaved": (interleaved, (1, 0, 1)), "hooks on views": (views, (0, 0, 0)),
              "K detached": (detached_k, (0, 0, 0)), "V recomputed between the hooks": (recomputed_v, (1, 0, 1)),
-             "V modified in place between the hooks": (v_inplace, (1, 0, 1)), "hooks under no_grad": (nograd_hooks, (1, 1, 0))}
+             "V modified in place between the hooks": (v_inplace, (1, 0, 1)), "hooks under no_grad": (nograd_hooks, (1, 1, 0)),
+             "results modified in place": (results_modified_in_place, (1, 1, 0))}
 
 
 @pytest.mark.parametrize("autocast", [False, True])

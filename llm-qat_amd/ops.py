@@ -523,9 +523,9 @@ def pair_forward(w, x, w_bits, a_bits, lo, hi, need_w, need_x, wide=False):
     return wq, xq, side_w, side_x, rows_w, rows_x, cols
 
 
-# ---- the module's hot path, lean: everything that depends only on (shapes, dtype, device) is decided once per module and shape
-# (`pair_plan`); what a call still does is allocate, read pointers and launch.  Same launches, same results as pair_forward /
-# pair_backward, which remain the general front-ends (views, wide results, mixed cases).
+# ---- the module's hot path: everything that depends only on (shapes, dtype, device) is decided once per module and shape (`pair_plan`);
+# the call itself -- allocate, launch, build the node -- is the C++ node's (csrc/fq_autograd_node.cpp::pair_forward).  Without the node,
+# pair_forward / pair_backward above serve (rounds 4-5 had lean Python twins of them here; the C++ node replaced those).
 def pair_plan(w, x):
     """-> (code, cols, rows_w, rows_x, mask bytes w, mask bytes x, device index) for a contiguous CUDA weight [out, in] and input [..., in] of
     one dtype that the two-tensor launch serves, else None"""
@@ -540,59 +540,6 @@ def pair_plan(w, x):
     if not mw or not mx:
         return None
     return code, cols, rows_w, rows_x, mw, mx, w.device.index
-
-
-def pair_forward_planned(w, x, plan, w_bits, a_bits, need_w, need_x, ac):
-    """pair_forward for contiguous operands with a plan; ac: autocast arithmetic, results rounded once to the operand dtype (the caller has
-    checked autocast_narrow_ok).  -> (wq, xq, side_w, side_x, rows_w, rows_x, cols) or None (not served: the general path decides)"""
-    code, cols, rows_w, rows_x, mw, mx, dev = plan
-    wq, xq = torch.empty_like(w), torch.empty_like(x)
-    pw = px = bw = bx = None
-    side_w = side_x = None
-    if need_w:
-        side_w = torch.empty(rows_w * 8 + mw, dtype=torch.uint8, device=w.device)
-        pw = side_w.data_ptr()
-        bw = pw + rows_w * 8
-    if need_x:
-        side_x = torch.empty(rows_x * 8 + mx, dtype=torch.uint8, device=w.device)
-        px = side_x.data_ptr()
-        bx = px + rows_x * 8
-    cur = _cur_dev()
-    fn = _lib.lib().fq_sym_fwd_pair
-    if dev == cur:
-        rc = fn(w.data_ptr(), wq.data_ptr(), rows_w, w_bits, pw, bw, mw if need_w else 0, x.data_ptr(), xq.data_ptr(), rows_x, a_bits, px, bx, mx if need_x else 0,
-                cols, code, _SEM_AUTOCAST if ac else _semantics, 1 if ac else 0, -2.0, 2.0, _raw_stream(cur))
-    else:
-        with torch.cuda.device(dev):
-            rc = fn(w.data_ptr(), wq.data_ptr(), rows_w, w_bits, pw, bw, mw if need_w else 0, x.data_ptr(), xq.data_ptr(), rows_x, a_bits, px, bx, mx if need_x else 0,
-                    cols, code, _SEM_AUTOCAST if ac else _semantics, 1 if ac else 0, -2.0, 2.0, _raw_stream(dev))
-    if rc:
-        if rc == _lib.ERR_UNSUPPORTED:
-            return None
-        _lib.check(rc, "quantize_pair")
-    return wq, xq, side_w, side_x, rows_w, rows_x, cols
-
-
-def pair_backward_planned(gw, gx, side_w, side_x, rows_w, rows_x, cols, code, inplace_w):
-    """pair_backward for two contiguous, 16-byte aligned gradients of the planned dtype, clip [-2, 2] (the module's own): -> (ow, ox) or None"""
-    pgw, pgx = gw.data_ptr(), gx.data_ptr()
-    if (pgw | pgx) & 15 or not (gw.is_contiguous() and gx.is_contiguous()):
-        return None
-    ow = gw if inplace_w else torch.empty_like(gw)
-    ox = torch.empty_like(gx)
-    pw, px = side_w.data_ptr(), side_x.data_ptr()
-    dev, cur = gw.device.index, _cur_dev()
-    fn = _lib.lib().fq_ste_bwd_mask_pair
-    if dev == cur:
-        rc = fn(pgw, ow.data_ptr(), rows_w, pw, pw + rows_w * 8, pgx, ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, -2.0, 2.0, code, _raw_stream(cur))
-    else:
-        with torch.cuda.device(dev):
-            rc = fn(pgw, ow.data_ptr(), rows_w, pw, pw + rows_w * 8, pgx, ox.data_ptr(), rows_x, px, px + rows_x * 8, cols, -2.0, 2.0, code, _raw_stream(dev))
-    if rc:
-        if rc == _lib.ERR_UNSUPPORTED:
-            return None
-        _lib.check(rc, "quantize_linear_pair_backward")
-    return ow, ox
 
 
 def weight_forward(w, w_bits, lo, hi, need):

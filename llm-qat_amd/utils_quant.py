@@ -806,16 +806,12 @@ class _PairNode(torch.autograd.Function):
     @staticmethod
     @_graph_aware
     def backward(ctx, gw, gx):
-        # (runs on the autograd engine's device thread, where every line of Python costs 2-3x what it costs on the caller's:
-        # tools/host_pieces.py -- hence the straight-line fast path for the ordinary case)
+        # (runs on the autograd engine's device thread, where every line of Python costs 2-3x what it costs on the caller's --
+        # tools/host_pieces.py --: the straight-line case is the C++ node's, this is the general form and the node's way out)
         inplace_w = _INPLACE_WGRAD and gw is not None and not ctx.fq_foreign and _inplace_ok(gw)
         rows_w, rows_x, cols, code, dtype, st = ctx.fq
         _backward_started(st)
         side_w, side_x = ctx.saved_tensors
-        if gw is not None and gx is not None and gw.dtype is dtype and gx.dtype is dtype and side_w is not None and side_x is not None:
-            out = ops.pair_backward_planned(gw, gx, side_w, side_x, rows_w, rows_x, cols, code, inplace_w)
-            if out is not None:
-                return out[0], out[1], None, None, None
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_w and gw is not None and gw.dtype != dtype:
             gw, inplace_w = gw.to(dtype), _INPLACE_WGRAD   # a fresh tensor of our own
@@ -1230,7 +1226,7 @@ class QuantizeLinear(nn.Linear):
                 return self._pair_forward_general(input_)
             side_x = out[2]
         else:
-            res = ops.pair_forward_planned(weight, input_, pp, self.w_bits, self.a_bits, need_w, need_x, ac)
+            res = ops.pair_forward(weight, input_, self.w_bits, self.a_bits, -2.0, 2.0, need_w, need_x)
             if res is None:
                 return self._pair_forward_general(input_)
             out = _PairNode.apply(weight, input_, res, pp[0], False) if (need_w or need_x) else (res[0], res[1])

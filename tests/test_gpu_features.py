@@ -170,9 +170,8 @@ def test_low_bit_fused_row_mean(pkg):
 
 
 class Counter:
-    """counts calls of the named `ops` functions; pair_forward / pair_backward stand for their lean twins of the module's hot path too
-    (ops.pair_forward_planned / pair_backward_planned: same launches)"""
-    TWINS = {"pair_forward": "pair_forward_planned", "pair_backward": "pair_backward_planned"}
+    """counts calls of the named `ops` functions, and the launches the C++ autograd nodes make of the same entry points"""
+    TWINS = {}
 
     # the C++ node's own launches of the same entry points (a sibling's weight-only launch is one of the three single-tensor forwards in Python)
     CPP = {"pair_forward": "cpp_pair_forward", "pair_backward": "cpp_pair_backward", "train_forward": "cpp_weight_forward",

@@ -130,7 +130,6 @@ def timed(name, f):
 
 UQ._PairNode.backward = staticmethod(timed("node", orig_node))
 ops.pair_backward = timed("pair_backward", orig_pb)
-ops.pair_backward_planned = timed("pair_backward", ops.pair_backward_planned)
 _NoGemm.backward = staticmethod(timed("nogemm", orig_ng))
 tot = 0.0
 M = 320

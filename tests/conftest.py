@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     """Build what is missing or stale (the .so files are git-ignored): the HIP library with hipcc
-    (cross-compiles for gfx950 without a GPU, ~40 s) and the CPU oracle with gcc.  Failures surface in
+    (cross-compiles for gfx950 without a GPU, ~70 s), the C++ autograd node with g++ and the CPU oracle with gcc.  Failures surface in
     the tests that need the artefact, not here."""
     import importlib.util
     try:
@@ -27,6 +27,10 @@ def pytest_sessionstart(session):
         mod.build_extension()
     except Exception as e:  # noqa: BLE001
         print(f"[conftest] HIP library build skipped/failed: {e!r}", file=sys.stderr)
+    try:
+        mod.build_node()        # the C++ autograd node (g++ against this interpreter's PyTorch, ~30 s): before the package is first imported
+    except Exception as e:  # noqa: BLE001
+        print(f"[conftest] C++ autograd node build skipped/failed: {e!r} (its tests will say so)", file=sys.stderr)
     try:
         from oracle import oracle as O
         O.build()

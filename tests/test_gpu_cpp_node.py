@@ -335,11 +335,12 @@ def test_no_growth_over_many_steps(pkg):
         gc.collect()
         return torch.cuda.memory_allocated(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss, sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor))
 
-    run(100)
+    run(300)
     dev0, rss0, n0 = run(100)
     dev1, rss1, n1 = run(2000)
     assert dev1 == dev0, (dev0, dev1)
     assert n1 <= n0 + 2, (n0, n1)
-    assert rss1 - rss0 < 32 * 1024, f"host memory grew by {(rss1 - rss0) / 1024:.1f} MiB over 2 000 steps"     # ru_maxrss is in KiB
+    # (the peak resident set, in KiB: a coarse net -- a tensor or a side buffer kept per step would be gigabytes here -- under the two exact ones above)
+    assert rss1 - rss0 < 64 * 1024, f"host memory grew by {(rss1 - rss0) / 1024:.1f} MiB over 2 000 steps"
     st = pkg.stats()
     assert st.get("cpp_pair_backward", 0) >= 7 * 2000 and st.get("cpp_one_backward_wide", 0) >= 2 * 2000, st

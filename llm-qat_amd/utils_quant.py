@@ -62,22 +62,23 @@ def _clip_pair(clip_val):
 # ---- counters of what the stateful host logic did (llm_qat_amd.stats()): every optimisation below that can silently fall back says so here
 _stats = {}
 
-# The C++ autograd node (csrc/fq_autograd_node.cpp): QuantizeLinear's straight-line path without Python on the autograd engine's thread.
-# Optional: without the file (or with LLMQAT_AMD_CPP_NODE=0 / cpp_node(False)) the Python `_PairNode` below serves -- same launches, same
-# bits.  It is bound to the kernel library on first use and calibrates its in-place guard at the end of this module.
+# The C++ autograd nodes (csrc/fq_autograd_node.cpp): the straight-line cases -- a QuantizeLinear's operand pair, a sibling's weight-only launch,
+# K and V at the KV-cache hooks, a bare SymQuantizer / AsymQuantizer.apply in mask mode -- without Python on the autograd engine's thread.
+# Optional: without the file (or with LLMQAT_AMD_CPP_NODE=0 / cpp_node(False)) the Python nodes below serve -- same launches, same bits --
+# and everything off the straight line is theirs anyway.  Bound to the kernel library and calibrated at the end of this module.
 _cnode = _node.load()
 _USE_CNODE = _cnode is not None
 
 
 def cpp_node(flag=True):
-    """use the C++ autograd node for QuantizeLinear's operand pair (default: on when _fq_node.so is built)"""
+    """use the C++ autograd nodes (default: on when _fq_node.so is built and loads); -> whether they are in use now"""
     global _USE_CNODE
     _USE_CNODE = bool(flag) and _cnode is not None and _cnode_ready
     return _USE_CNODE
 
 
 def host_node():
-    """-> "c++" or "python (<why>)": which autograd node QuantizeLinear's straight-line path builds"""
+    """-> "c++" or "python (<why>)": which autograd nodes the straight-line paths build"""
     return "c++" if _USE_CNODE else "python (%s)" % (_node.status() if _cnode is None else ("guard not calibrated" if not _cnode_ready else "switched off"))
 
 
